@@ -1,0 +1,322 @@
+/*
+ * gpt.h -- C-ABI of the MI355X path-tracing hot path (libgpt_hip.so).
+ *
+ * The library replaces ONE function of the reference renderer: the per-pass
+ * device entry point
+ *
+ *     extern "C" void launchKernel(int numPolys, Poly* polys, int numSpheres,
+ *                                  Sphere* spheres, int numPixels, Color* pixels,
+ *                                  int counter, Camera renderCamera);
+ *
+ * declared at  GPUPathTracer/GPUPathTracer/path_tracer_kernel.h:9-10  and
+ * defined at   GPUPathTracer/GPUPathTracer/path_tracer_kernel.cu:760-882.
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No C++ or torch types.
+ * All functions except launchKernel return a gpt_status; launchKernel keeps
+ * the reference's convention (print to stderr + exit(EXIT_FAILURE),
+ * cuda_safe_call.h:6-12).
+ */
+#ifndef GPT_H
+#define GPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#else
+#include <stdbool.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Scene PODs.  Byte-for-byte the reference layouts, so a host array prepared */
+/* for the reference can be handed over unchanged.  Define                    */
+/* GPT_NO_POD_TYPES before including this header when the reference's own     */
+/* headers (camera.h, sphere.h, ...) are already in the translation unit.     */
+/* ------------------------------------------------------------------------- */
+#ifndef GPT_NO_POD_TYPES
+
+#if !defined(__VECTOR_TYPES_H__) && !defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H) && !defined(GPT_HAVE_VECTOR_TYPES)
+/* CUDA's float3 is 12 bytes, 4-aligned; float2 is 8 bytes, 8-aligned. */
+typedef struct gpt_float3 { float x, y, z; } gpt_float3;
+#if defined(__cplusplus)
+typedef struct alignas(8) gpt_float2 { float x, y; } gpt_float2;
+#else
+typedef struct gpt_float2 { _Alignas(8) float x; float y; } gpt_float2;
+#endif
+#define GPT_FLOAT3 gpt_float3
+#define GPT_FLOAT2 gpt_float2
+#else
+#define GPT_FLOAT3 float3
+#define GPT_FLOAT2 float2
+#endif
+
+/* color.h:9 */
+typedef GPT_FLOAT3 Color;
+
+/* absorption_and_scattering_properties.h:7-12 (16 bytes) */
+typedef struct AbsorptionAndScatteringProperties {
+    Color absorptionCoefficient;
+    float reducedScatteringCoefficient;
+} AbsorptionAndScatteringProperties;
+
+/* medium.h:8-13 (20 bytes) */
+typedef struct Medium {
+    float refractiveIndex;
+    AbsorptionAndScatteringProperties absorptionAndScatteringProperties;
+} Medium;
+
+/* material.h:8-16 (60 bytes; hasTransmission is a 1-byte bool + 3 pad) */
+typedef struct Material {
+    Color diffuseColor;
+    Color emittedColor;
+    Color specularColor;
+    bool  hasTransmission;
+    Medium medium;
+} Material;
+
+/* sphere.h:7-14 (76 bytes) */
+typedef struct Sphere {
+    GPT_FLOAT3 position;
+    float radius;
+    Material material;
+} Sphere;
+
+/* poly.h:7-17 (120 bytes).  `position` is never read by the renderer. */
+typedef struct Poly {
+    GPT_FLOAT3 position;
+    GPT_FLOAT3 p0;
+    GPT_FLOAT3 p1;
+    GPT_FLOAT3 p2;
+    GPT_FLOAT3 n;
+    Material material;
+} Poly;
+
+/* ray.h:6-11 (24 bytes) */
+typedef struct Ray {
+    GPT_FLOAT3 origin;
+    GPT_FLOAT3 direction;
+} Ray;
+
+/* camera.h:6-14 (64 bytes: float2 is 8-aligned, so 4 pad bytes precede fov) */
+typedef struct Camera {
+    GPT_FLOAT2 resolution;
+    GPT_FLOAT3 position;
+    GPT_FLOAT3 view;
+    GPT_FLOAT3 up;
+    GPT_FLOAT2 fov;
+    float apertureRadius;
+    float focalDistance;
+} Camera;
+
+#if defined(__cplusplus)
+static_assert(sizeof(Color) == 12, "Color layout");
+static_assert(sizeof(AbsorptionAndScatteringProperties) == 16, "A&S layout");
+static_assert(sizeof(Medium) == 20, "Medium layout");
+static_assert(sizeof(Material) == 60, "Material layout");
+static_assert(sizeof(Sphere) == 76, "Sphere layout");
+static_assert(sizeof(Poly) == 120, "Poly layout");
+static_assert(sizeof(Ray) == 24, "Ray layout");
+static_assert(sizeof(Camera) == 64, "Camera layout");
+#else
+_Static_assert(sizeof(Material) == 60, "Material layout");
+_Static_assert(sizeof(Sphere) == 76, "Sphere layout");
+_Static_assert(sizeof(Poly) == 120, "Poly layout");
+_Static_assert(sizeof(Camera) == 64, "Camera layout");
+#endif
+
+#endif /* GPT_NO_POD_TYPES */
+
+/* ------------------------------------------------------------------------- */
+/* Status codes                                                               */
+/* ------------------------------------------------------------------------- */
+typedef enum gpt_status {
+    GPT_OK = 0,
+    GPT_ERR_INVALID_ARGUMENT = 1,
+    GPT_ERR_HIP = 2,            /* a HIP runtime call failed; see gpt_last_error() */
+    GPT_ERR_NO_DEVICE = 3,      /* no usable gfx950 device                           */
+    GPT_ERR_OUT_OF_MEMORY = 4,
+    GPT_ERR_IO = 5,
+    GPT_ERR_PARSE = 6,
+    GPT_ERR_TOO_LARGE = 7
+} gpt_status;
+
+/* Text of the last failure on the calling thread ("" if none). */
+const char* gpt_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Render parameters.  The reference hard-codes these as #defines             */
+/* (path_tracer_kernel.cu:46-50); gpt_render_params_default() returns exactly */
+/* those values except max_depth, which callers normally lower.               */
+/* ------------------------------------------------------------------------- */
+typedef struct gpt_render_params {
+    int   max_depth;          /* MAX_TRACE_DEPTH, 30                    (:47)  */
+    float ray_bias;           /* RAY_BIAS_DISTANCE, 0.0002f             (:48)  */
+    float min_ray_weight;     /* MIN_RAY_WEIGHT, 0.00001f  (compared in double)*/
+    float ground_elevation;   /* HARD_CODED_GROUND_ELEVATION, -0.8f     (:50)  */
+    int   ground_enabled;     /* 1: the infinite ground plane exists (as :510) */
+    /* Pixel -> (x,y).  0: the reference's arithmetic, row stride =
+     * resolution.y (:135-136; only right for square images).  1: row stride =
+     * resolution.x (right for any image).  Identical for square images.       */
+    int   row_stride_is_width;
+    /* 0: brute-force loop over every triangle, as the reference (:536-557).
+     * 1: kd-tree traversal returning the same hit as that loop.               */
+    int   use_kdtree;
+    int   kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64)  */
+    int   reserved[8];
+} gpt_render_params;
+
+void gpt_render_params_default(gpt_render_params* p);
+
+/* ------------------------------------------------------------------------- */
+/* Scene: device-resident geometry + kd-tree + per-path state buffers          */
+/* ------------------------------------------------------------------------- */
+typedef struct gpt_scene gpt_scene;
+
+/* Upload `spheres`/`polys` (HOST arrays in the reference layout, the arrays
+ * PathTracer::createDeviceData builds at path_tracer.cpp:116-278), build the
+ * kd-tree over the polys on the host and upload its flattened form.
+ * `device` is the HIP device ordinal. */
+gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres,
+                            const Poly* polys, int numPolys,
+                            const gpt_render_params* params, int device,
+                            gpt_scene** out_scene);
+gpt_status gpt_scene_destroy(gpt_scene* scene);
+
+/* (Re)size the per-pixel buffers for `numPixels` pixels and clear the
+ * accumulated image and its pass count (PathTracer::reset, path_tracer.cpp:88-91). */
+gpt_status gpt_scene_reset(gpt_scene* scene, int numPixels);
+
+/* One sample-per-pixel pass with seed `counter`; semantics of launchKernel:
+ * `host_pixels` (numPixels x 3 floats, may be NULL) receives THIS pass's
+ * radiance (overwritten, not accumulated) -- path_tracer_kernel.cu:869.
+ * The pass is also added into the scene's device-resident image, which is
+ * what PathTracer::render does on the host (path_tracer.cpp:100-103). */
+gpt_status gpt_render_pass(gpt_scene* scene, const Camera* camera, int counter,
+                           float* host_pixels);
+
+/* Passes counter_begin .. counter_end-1 back to back, no host round trip in
+ * between; image += each pass in counter order.  Asynchronous with respect to
+ * the host unless `sync` is non-zero. */
+gpt_status gpt_render_range(gpt_scene* scene, const Camera* camera,
+                            int counter_begin, int counter_end, int sync);
+
+/* Block until all queued work of the scene has finished. */
+gpt_status gpt_scene_sync(gpt_scene* scene);
+
+/* The accumulated image: sum over passes of per-pass radiance, numPixels x 4
+ * floats (r,g,b,passes) on the device / 3 floats per pixel on the host. */
+gpt_status gpt_accum_device_ptr(gpt_scene* scene, void** out_ptr, size_t* out_bytes);
+gpt_status gpt_accum_download(gpt_scene* scene, float* host_rgb, int* out_passes);
+/* Replace the accumulated image (e.g. with the RCCL-reduced one). */
+gpt_status gpt_accum_upload(gpt_scene* scene, const float* host_rgb, int passes);
+
+/* Work counters since the last gpt_scene_reset. */
+typedef struct gpt_stats {
+    uint64_t path_bounces;        /* sum over passes and depths of live paths  */
+    uint64_t live_at_depth[64];   /* live paths entering depth d, all passes   */
+    uint64_t passes;
+    uint64_t kd_nodes_visited;    /* only counted when built with stats on     */
+    uint64_t kd_tris_tested;
+    double   device_ms_trace;     /* HIP-event time of the intersect kernels   */
+    double   device_ms_total;     /* HIP-event time of whole passes            */
+    uint64_t trace_launches;
+} gpt_stats;
+gpt_status gpt_get_stats(gpt_scene* scene, gpt_stats* out);
+
+/* First-hit record of every primary ray of pass `counter` (debug/parity):
+ * prim[i] = -1 miss, -2 ground, 0x40000000|s sphere s, otherwise triangle
+ * index; t[i] = hit distance. Host arrays of numPixels entries. */
+gpt_status gpt_debug_primary_hits(gpt_scene* scene, const Camera* camera, int counter,
+                                  int32_t* prim, float* t);
+
+/* Closest hit of arbitrary rays against the scene's triangles only (no ground,
+ * no spheres), `use_kdtree` choosing traversal or the brute-force loop.
+ * rays: n x 6 floats (origin, direction) on the host. tri[i] = -1 on a miss. */
+gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int use_kdtree,
+                               int32_t* tri, float* t);
+
+/* ------------------------------------------------------------------------- */
+/* kd-tree (host builder).  Flattened form, all arrays owned by the tree:      */
+/*   nodes      : n_nodes x 2 uint32   {w0, w1}                                */
+/*      inner   : w0 = (left_child_index << 2) | axis (axis 0..2),             */
+/*                w1 = split position (float bits); right child = left + 1     */
+/*      leaf    : w0 = (first_ref << 2) | 3, w1 = number of triangle refs      */
+/*   refs       : n_refs  int32 triangle indices, leaf by leaf                 */
+/*   bounds     : 6 floats, root box min xyz / max xyz                         */
+/* ------------------------------------------------------------------------- */
+typedef struct gpt_kdtree gpt_kdtree;
+gpt_status gpt_kdtree_build(const float* tri_vertices /* n x 9 */, int n_tris,
+                            int small_threshold, gpt_kdtree** out_tree);
+gpt_status gpt_kdtree_info(const gpt_kdtree* tree, int* n_nodes, int* n_refs,
+                           int* max_depth, float bounds[6]);
+gpt_status gpt_kdtree_copy(const gpt_kdtree* tree, uint32_t* nodes /* 2*n_nodes */,
+                           int32_t* refs /* n_refs */);
+void       gpt_kdtree_free(gpt_kdtree* tree);
+
+/* ------------------------------------------------------------------------- */
+/* Reference-compatible entry point.                                          */
+/* `polys` and `spheres` are DEVICE pointers to arrays in the reference        */
+/* layout (as cudaMalloc'ed at path_tracer.cpp:281-284); `pixels` is a HOST    */
+/* buffer of numPixels float3, overwritten with this pass's radiance.          */
+/* The scene behind (polys, spheres) is uploaded/re-indexed on first use and   */
+/* whenever the arrays' contents change.  Depth and the other constants are    */
+/* the reference's (30 bounces etc.) unless overridden with                    */
+/* gpt_launch_kernel_params().  Errors: message on stderr + exit(1).           */
+/* ------------------------------------------------------------------------- */
+#ifndef GPT_NO_POD_TYPES
+void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres,
+                  int numPixels, Color* pixels, int counter, Camera renderCamera);
+#endif
+/* Parameters used by subsequent launchKernel calls (NULL restores defaults). */
+void gpt_launch_kernel_params(const gpt_render_params* params);
+/* Device-memory helpers for callers of launchKernel that have no HIP runtime
+ * of their own (the reference used cudaMalloc/cudaMemcpy/cudaFree). */
+gpt_status gpt_device_alloc(void** out_ptr, size_t bytes);
+gpt_status gpt_device_upload(void* dst_device, const void* src_host, size_t bytes);
+gpt_status gpt_device_free(void* ptr);
+
+/* ------------------------------------------------------------------------- */
+/* Callers and data formats either side of the path                            */
+/* ------------------------------------------------------------------------- */
+
+/* OBJ loading with the reference loader's semantics (objcore/objloader.cpp:18-122)
+ * followed by PathTracer::prepMesh's face -> Poly conversion (path_tracer.cpp:52-69):
+ * first three vertices of each face; normal = the normal at the face's first
+ * normal index (not renormalised).  Faces given without normals get
+ * normalize(cross(p1-p0, p2-p0)) (as obj.cpp:87-89 does for its VBOs) instead
+ * of the reference's out-of-range read.  Polys get position (0,-0.8,0) and
+ * `material` (path_tracer.cpp:275-278).  *out_polys is malloc'ed; free with
+ * gpt_free(). bbox (may be NULL): min xyz, max xyz over all `v` lines. */
+gpt_status gpt_obj_load(const char* path, const Material* material,
+                        Poly** out_polys, int* out_numPolys, float bbox[6]);
+void gpt_free(void* p);
+
+/* The reference's default scene: the 14 spheres of path_tracer.cpp:217-271. */
+int  gpt_default_scene_sphere_count(void);
+void gpt_default_scene(Sphere* out_spheres /* 14 entries */);
+/* Named material presets of path_tracer.cpp:124-215 ("red", "green", "orange",
+ * "purple", "glass", "greenGlass", "marble", "something", "ketchup", "white",
+ * "lightBlue", "gold", "steel", "light").  Returns GPT_ERR_INVALID_ARGUMENT
+ * for an unknown name. */
+gpt_status gpt_material_preset(const char* name, Material* out);
+
+/* InteractiveCamera defaults + buildRenderCamera (interactive_camera.cpp:15-25,
+ * 66-87; display.cpp:78-85): orbit camera around `center`. */
+void gpt_orbit_camera(float width, float height, float fovx_degrees,
+                      float yaw, float pitch, float radius, float apertureRadius,
+                      const float center[3], Camera* out);
+void gpt_default_camera(float width, float height, Camera* out);
+
+/* floatTo8Bit(sum / passes) per pixel (color.cpp:41-62, display.cpp:195-200):
+ * gamma 1/2.2, scale 255, clamp, truncate.  out: numPixels x 3 bytes. */
+void gpt_tonemap_8bit(const float* sum_rgb, int numPixels, int passes, unsigned char* out_rgb8);
+/* Binary PPM (P6) of the tone-mapped image, row 0 at the top. */
+gpt_status gpt_write_ppm(const char* path, const float* sum_rgb, int width, int height, int passes);
+/* Little-endian PFM (PF) of sum/passes, raw float radiance. */
+gpt_status gpt_write_pfm(const char* path, const float* sum_rgb, int width, int height, int passes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPT_H */

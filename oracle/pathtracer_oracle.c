@@ -1,0 +1,589 @@
+/*
+ * pathtracer_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, CPU restatement of the reference's per-pass device code
+ * (GPUPathTracer/GPUPathTracer/path_tracer_kernel.cu), used only as the
+ * checker in tests/, in __graft_entry__.smoke() and as bench.py's
+ * cpu_baseline leg.  Nothing in the shipped library links or calls it.
+ *
+ * Pinning status: the reference ships no tests, golden images or known-answer
+ * vectors, and its launcher cannot be built in this image (it needs the CUDA
+ * toolkit headers and Thrust; writing stand-ins for them is not done).  The
+ * restatement is therefore pinned by (1) the Thrust documentation KAT for
+ * minstd_rand (10000th draw == 399268537), (2) the randhash / uniform values
+ * and the render statistics recorded from a host run of the reference kernel
+ * text during the survey of the reference (see tests/golden/README.md), and
+ * otherwise "parity unpinned" by the reference's own fixtures (none exist).
+ *
+ * Arithmetic follows what a host C++ compiler makes of the reference text:
+ * double sub-expressions where a double literal or pow(float,int) appears,
+ * float everywhere else, no fused multiply-add (build with -ffp-contract=off).
+ */
+#include "../include/gpt.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef gpt_float3 f3;
+
+/* path_tracer_kernel.cu:54-57 (double literals, digits as written there) */
+#define ORC_PI      3.1415926535897932384626422832795028841971
+#define ORC_TWO_PI  6.2831853071795864769252867665590057683943
+#define ORC_SQRT13  0.5773502691896257645091487805019574556476
+#define ORC_E       2.7182818284590452353602874713526624977572
+/* medium.h:17 */
+#define ORC_AIR_IOR 1.000293
+
+/* ---- cutil_math.h float3 semantics ------------------------------------- */
+static inline f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+/* cutil_math.h:1123-1126 */
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* cutil_math.h:1295-1298 */
+static inline f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* cutil_math.h:1166-1168 */
+static inline float length3(f3 v) { return sqrtf(dot3(v, v)); }
+/* cutil_math.h:1184-1188 with the host rsqrtf of :58-61 (1.0f / sqrtf) */
+static inline f3 normalize3(f3 v) {
+    float invLen = 1.0f / sqrtf(dot3(v, v));
+    return scale3(v, invLen);
+}
+
+/* ---- path_tracer_kernel.cu:75-84 ---------------------------------------- */
+uint32_t orc_randhash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+/* ---- thrust::default_random_engine == minstd_rand ----------------------- */
+/* linear_congruential_engine<uint32, 48271, 0, 2147483647>; seeding and the
+ * uniform_real_distribution<float> mapping as in Thrust's
+ * detail/linear_congruential_engine.inl and detail/uniform_real_distribution.inl
+ * (call sites path_tracer_kernel.cu:139-142, 492-493). */
+typedef struct { uint32_t x; } orc_rng;
+
+static inline void rng_seed(orc_rng* g, uint32_t s) {
+    uint32_t r = s % 2147483647u;
+    g->x = (r == 0u) ? 1u : r;
+}
+static inline uint32_t rng_next(orc_rng* g) {
+    g->x = (uint32_t)(((uint64_t)g->x * 48271u) % 2147483647u);
+    return g->x;
+}
+/* min() == 1, max() == m-1; float(max-min) == 2^31 and 1.0f + 2^31 == 2^31. */
+static inline float rng_uniform(orc_rng* g) {
+    float result = (float)(rng_next(g) - 1u);
+    result /= (1.0f + (float)(2147483646u - 1u));
+    return (result * (1.0f - 0.0f)) + 0.0f;
+}
+
+/* Exposed for the known-answer tests. */
+uint32_t orc_minstd_nth(uint32_t seed, int n) {
+    orc_rng g; rng_seed(&g, seed);
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) v = rng_next(&g);
+    return v;
+}
+void orc_uniform_stream(uint32_t seed, int n, float* out) {
+    orc_rng g; rng_seed(&g, seed);
+    for (int i = 0; i < n; i++) out[i] = rng_uniform(&g);
+}
+
+/* ---- parameters ---------------------------------------------------------- */
+typedef struct orc_params {
+    int   max_depth;            /* MAX_TRACE_DEPTH (:47) */
+    float ray_bias;             /* RAY_BIAS_DISTANCE (:48), narrowed to float at :659 */
+    double min_ray_weight;      /* MIN_RAY_WEIGHT (:49), compared in double */
+    float ground_elevation;     /* HARD_CODED_GROUND_ELEVATION (:50), a float argument at :510 */
+    int   ground_enabled;
+    int   row_stride_is_width;  /* 0 = the reference's :135-136 arithmetic */
+} orc_params;
+
+void orc_params_default(orc_params* p) {
+    p->max_depth = 30;
+    p->ray_bias = (float)0.0002;
+    p->min_ray_weight = 0.00001;
+    p->ground_elevation = (float)-0.8;
+    p->ground_enabled = 1;
+    p->row_stride_is_width = 0;
+}
+
+/* ---- raycastFromCameraKernel, one pixel (:125-191) ----------------------- */
+static void raycast_pixel(Camera cam, int pixelIndex, uint32_t seed,
+                          const orc_params* P, Ray* out) {
+    float stride = P->row_stride_is_width ? cam.resolution.x : cam.resolution.y;
+    int y = (int)(pixelIndex / stride);
+    int x = (int)(pixelIndex - (y * stride));
+
+    orc_rng rng;
+    rng_seed(&rng, orc_randhash(seed) * orc_randhash((uint32_t)pixelIndex) * orc_randhash(seed));
+    float jitterValueX = (float)(rng_uniform(&rng) - 0.5);
+    float jitterValueY = (float)(rng_uniform(&rng) - 0.5);
+
+    cam.view = normalize3(cam.view);
+    f3 horizontalAxis = normalize3(cross3(cam.view, cam.up));
+    f3 verticalAxis = normalize3(cross3(horizontalAxis, cam.view));
+
+    f3 middle = add3(cam.position, cam.view);
+    f3 horizontal = scale3(horizontalAxis, (float)tan(cam.fov.x * 0.5 * (ORC_PI / 180)));
+    f3 vertical = scale3(verticalAxis, (float)tan(-cam.fov.y * 0.5 * (ORC_PI / 180)));
+
+    float sx = (jitterValueX + x) / (cam.resolution.x - 1);
+    float sy = (jitterValueY + y) / (cam.resolution.y - 1);
+
+    f3 onePlane = add3(add3(middle, scale3(horizontal, (2 * sx) - 1)),
+                       scale3(vertical, (2 * sy) - 1));
+    f3 onImagePlane = add3(cam.position,
+                           scale3(sub3(onePlane, cam.position), cam.focalDistance));
+
+    f3 aperturePoint;
+    if (cam.apertureRadius > 0.00001) {
+        float random1 = rng_uniform(&rng);
+        float random2 = rng_uniform(&rng);
+        float angle = (float)(ORC_TWO_PI * random1);
+        float distance = cam.apertureRadius * sqrtf(random2);
+        float apertureX = cosf(angle) * distance;
+        float apertureY = sinf(angle) * distance;
+        aperturePoint = add3(add3(cam.position, scale3(horizontalAxis, apertureX)),
+                             scale3(verticalAxis, apertureY));
+    } else {
+        aperturePoint = cam.position;
+    }
+    out->direction = normalize3(sub3(onImagePlane, aperturePoint));
+    out->origin = aperturePoint;
+}
+
+/* ---- intersection helpers ------------------------------------------------ */
+/* :194-197 */
+static inline f3 position_along_ray(const Ray* r, float t) {
+    return add3(r->origin, scale3(r->direction, t));
+}
+/* :200-219 */
+static float ground_intersection(float elevation, const Ray* r, f3* normal) {
+    if (r->direction.y != 0) {
+        double t = (elevation - r->origin.y) / r->direction.y;
+        *normal = mk3(0, 1, 0);
+        return (float)t;
+    }
+    return -1;
+}
+/* :226-248 */
+static int triangle_intersect(f3 a, f3 b, f3 c, f3 o, f3 d, float* lambda, float* bary1, float* bary2) {
+    f3 edge1 = sub3(b, a);
+    f3 edge2 = sub3(c, a);
+    f3 pvec = cross3(d, edge2);
+    float det = dot3(edge1, pvec);
+    if (det == 0.f) return 0;
+    float inv_det = 1.0f / det;
+    f3 tvec = sub3(o, a);
+    *bary1 = dot3(tvec, pvec) * inv_det;
+    f3 qvec = cross3(tvec, edge1);
+    *bary2 = dot3(d, qvec) * inv_det;
+    *lambda = dot3(edge2, qvec) * inv_det;
+    return (*bary1 >= 0.0f && *bary2 >= 0.0f && (*bary1 + *bary2) <= 1.0f);
+}
+/* :250-281 */
+static float sphere_intersection(const Sphere* s, const Ray* r, f3* normal) {
+    f3 v = sub3(r->origin, s->position);
+    float vDotDirection = dot3(v, r->direction);
+    float radicand = vDotDirection * vDotDirection - (dot3(v, v) - s->radius * s->radius);
+    if (radicand < 0) return -1;
+    float squareRoot = sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+    float t;
+    if (t1 < 0 && t2 < 0) {
+        return -1;
+    } else if (t1 > 0 && t2 > 0) {
+        t = (t1 < t2) ? t1 : t2;
+    } else {
+        t = (t1 > t2) ? t1 : t2;
+    }
+    f3 p = position_along_ray(r, t);
+    *normal = normalize3(sub3(p, s->position));
+    return t;
+}
+
+/* ---- sampling / BSDF helpers --------------------------------------------- */
+/* :352-374 */
+static f3 cosine_weighted_direction(f3 normal, float xi1, float xi2) {
+    float up = sqrtf(xi1);
+    float over = sqrtf(1 - up * up);
+    float around = (float)(xi2 * ORC_TWO_PI);
+    f3 directionNotNormal;
+    if (fabsf(normal.x) < ORC_SQRT13) {
+        directionNotNormal = mk3(1, 0, 0);
+    } else if (fabsf(normal.y) < ORC_SQRT13) {
+        directionNotNormal = mk3(0, 1, 0);
+    } else {
+        directionNotNormal = mk3(0, 0, 1);
+    }
+    f3 perpendicular1 = normalize3(cross3(normal, directionNotNormal));
+    f3 perpendicular2 = cross3(normal, perpendicular1);
+    return add3(add3(scale3(normal, up), scale3(perpendicular1, cosf(around) * over)),
+                scale3(perpendicular2, sinf(around) * over));
+}
+/* :376-385 */
+static f3 direction_in_sphere(float xi1, float xi2) {
+    float up = xi1 * 2 - 1;
+    float over = sqrtf(1 - up * up);
+    float around = (float)(xi2 * ORC_TWO_PI);
+    return mk3(up, cosf(around) * over, sinf(around) * over);
+}
+/* :387-390 */
+static f3 reflection_direction(f3 normal, f3 incident) {
+    return sub3(scale3(normal, (float)(2.0 * dot3(normal, incident))), incident);
+}
+/* :392-411; pow(float, int) is evaluated in double on the host */
+static f3 transmission_direction(f3 normal, f3 incident, float iorIncident, float iorTransmitted) {
+    float cosTheta1 = dot3(normal, incident);
+    float n1_n2 = iorIncident / iorTransmitted;
+    float radicand = (float)(1 - pow(n1_n2, 2) * (1 - pow(cosTheta1, 2)));
+    if (radicand < 0) return mk3(0, 0, 0);
+    float cosTheta2 = sqrtf(radicand);
+    f3 minusIncident = scale3(incident, -1);
+    if (cosTheta1 > 0) {
+        return add3(scale3(minusIncident, n1_n2), scale3(normal, n1_n2 * cosTheta1 - cosTheta2));
+    } else {
+        return add3(scale3(minusIncident, n1_n2), scale3(normal, n1_n2 * cosTheta1 + cosTheta2));
+    }
+}
+/* :413-456, reflectionCoefficient only */
+static float fresnel_reflection(f3 normal, f3 incident, float n1, float n2, f3 transmissionDirection) {
+    if (length3(transmissionDirection) <= 0.12345 || dot3(normal, transmissionDirection) > 0) {
+        return 1;
+    }
+    float cosThetaIncident = dot3(normal, incident);
+    float cosThetaTransmitted = dot3(scale3(normal, -1), transmissionDirection);
+    float rs = (float)pow((n1 * cosThetaIncident - n2 * cosThetaTransmitted) /
+                          (n1 * cosThetaIncident + n2 * cosThetaTransmitted), 2);
+    float rp = (float)pow((n1 * cosThetaTransmitted - n2 * cosThetaIncident) /
+                          (n1 * cosThetaTransmitted + n2 * cosThetaIncident), 2);
+    return (float)((rs + rp) / 2.0);
+}
+/* :458-466 */
+static f3 background_color(f3 direction) {
+    float position = (dot3(direction, normalize3(mk3((float)-0.5, (float)0.5, (float)-1.0))) + 1) / 2;
+    f3 firstColor = mk3((float)0.15, (float)0.3, (float)0.5);
+    f3 secondColor = mk3((float)1.0, (float)1.0, (float)1.0);
+    f3 interpolated = add3(scale3(firstColor, 1 - position), scale3(secondColor, position));
+    float radianceMultiplier = (float)1.0;
+    return scale3(interpolated, radianceMultiplier);
+}
+/* :468-475 */
+static f3 transmission_color(f3 absorption, float distance) {
+    f3 t;
+    t.x = powf((float)ORC_E, (float)(-1 * absorption.x * distance));
+    t.y = powf((float)ORC_E, (float)(-1 * absorption.y * distance));
+    t.z = powf((float)ORC_E, (float)(-1 * absorption.z * distance));
+    return t;
+}
+
+static void set_air_as(AbsorptionAndScatteringProperties* p) {
+    p->absorptionCoefficient = mk3(0, 0, 0);
+    p->reducedScatteringCoefficient = 0;
+}
+static void set_air_medium(Medium* m) {
+    m->refractiveIndex = (float)ORC_AIR_IOR;
+    set_air_as(&m->absorptionAndScatteringProperties);
+}
+static void set_default_material(Material* m) {
+    memset(m, 0, sizeof(*m));
+    m->diffuseColor = mk3(0, 0, 0);
+    m->emittedColor = mk3(0, 0, 0);
+    m->specularColor = mk3(0, 0, 0);
+    m->hasTransmission = 0;
+    set_air_medium(&m->medium);
+}
+
+/* Closest-hit record of one traceRayKernel invocation (for parity of hits). */
+typedef struct orc_hit {
+    int32_t prim;   /* -1 miss, -2 ground, 0x40000000|i sphere i, else triangle index */
+    float   t;
+} orc_hit;
+
+/* ---- traceRayKernel, one active path (:477-725) --------------------------
+ * State of the path is passed by pointer (the reference indexes its per-pixel
+ * arrays by pixelIndex).  Returns 1 while the path stays alive, 0 when the
+ * reference would write -1 into activePixels. */
+static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
+                      int pixelIndex, int rayDepth, uint32_t seedOrPass, const orc_params* P,
+                      Ray* ray, AbsorptionAndScatteringProperties* medium,
+                      f3* notAbsorbed, f3* accumulated, orc_hit* hit_out) {
+    Ray currentRay = *ray;
+    orc_rng rng;
+    rng_seed(&rng, orc_randhash(seedOrPass) * orc_randhash((uint32_t)pixelIndex) *
+                       orc_randhash((uint32_t)rayDepth));
+
+    float bestT = 123456789;
+    f3 bestNormal = mk3(0, 0, 0);
+    int bestIsGroundPlane = 0, bestIsSphere = 0, bestIsPoly = 0;
+    int bestSphereIndex = -1, bestPolyIndex = -1;
+    float t;
+    f3 normal;
+
+    if (P->ground_enabled) {
+        t = ground_intersection(P->ground_elevation, &currentRay, &normal);
+        if (t > 0) {
+            bestT = t; bestNormal = normal;
+            bestIsGroundPlane = 1; bestIsSphere = 0; bestIsPoly = 0;
+        }
+    }
+    for (int i = 0; i < numSpheres; i++) {
+        t = sphere_intersection(&spheres[i], &currentRay, &normal);
+        if (t > 0 && t < bestT) {
+            bestT = t; bestNormal = normal;
+            bestIsGroundPlane = 0; bestIsSphere = 1; bestIsPoly = 0;
+            bestSphereIndex = i;
+        }
+    }
+    for (int i = 0; i < numPolys; i++) {
+        float pt, ob1, ob2;
+        if (triangle_intersect(polys[i].p0, polys[i].p1, polys[i].p2,
+                               currentRay.origin, currentRay.direction, &pt, &ob1, &ob2)) {
+            t = pt;
+            if (t > 0 && t < bestT) {
+                bestT = t; bestNormal = polys[i].n;
+                bestIsGroundPlane = 0; bestIsSphere = 0; bestIsPoly = 1;
+                bestPolyIndex = i;
+            }
+        }
+    }
+    if (hit_out) {
+        hit_out->t = bestT;
+        hit_out->prim = bestIsGroundPlane ? -2 : bestIsSphere ? (0x40000000 | bestSphereIndex)
+                       : bestIsPoly ? bestPolyIndex : -1;
+    }
+
+    /* absorption and scattering (:561-597) */
+    {
+        AbsorptionAndScatteringProperties cur = *medium;
+        if (cur.reducedScatteringCoefficient > 0 ||
+            dot3(cur.absorptionCoefficient, cur.absorptionCoefficient) > 0.00001) {
+            float xiDistance = rng_uniform(&rng);
+            float scatteringDistance = -logf(xiDistance) / medium->reducedScatteringCoefficient;
+            if (scatteringDistance < bestT) {
+                Ray nextRay;
+                nextRay.origin = position_along_ray(&currentRay, scatteringDistance);
+                float xi1 = rng_uniform(&rng);
+                float xi2 = rng_uniform(&rng);
+                nextRay.direction = direction_in_sphere(xi1, xi2);
+                *ray = nextRay;
+                *notAbsorbed = mul3(*notAbsorbed,
+                                    transmission_color(cur.absorptionCoefficient, scatteringDistance));
+                if (length3(*notAbsorbed) <= P->min_ray_weight) return 0;
+                return 1;
+            } else {
+                *notAbsorbed = mul3(*notAbsorbed, transmission_color(cur.absorptionCoefficient, bestT));
+            }
+        }
+    }
+
+    if (bestIsGroundPlane || bestIsSphere || bestIsPoly) {
+        Material bestMaterial;
+        if (bestIsGroundPlane) {
+            set_default_material(&bestMaterial);
+            bestMaterial.diffuseColor = mk3((float)0.455, (float)0.43, (float)0.39);
+        } else if (bestIsSphere) {
+            bestMaterial = spheres[bestSphereIndex].material;
+        } else {
+            bestMaterial = polys[bestPolyIndex].material;
+        }
+
+        f3 incident = neg3(currentRay.direction);
+        Medium incidentMedium;
+        set_air_medium(&incidentMedium);
+        Medium transmittedMedium = bestMaterial.medium;
+
+        int backFace = (dot3(bestNormal, incident) < 0);
+        if (backFace) {
+            bestNormal = scale3(bestNormal, -1);
+            Medium tmp = incidentMedium;
+            incidentMedium = transmittedMedium;
+            transmittedMedium = tmp;
+        }
+
+        f3 reflectionDirection = reflection_direction(bestNormal, incident);
+        f3 transmissionDirection = transmission_direction(bestNormal, incident,
+                                                          incidentMedium.refractiveIndex,
+                                                          transmittedMedium.refractiveIndex);
+        f3 bestIntersectionPoint = position_along_ray(&currentRay, bestT);
+        f3 biasVector = scale3(bestNormal, P->ray_bias);
+
+        int doSpecular = (bestMaterial.medium.refractiveIndex > 1.0);
+        float rouletteRandomFloat = rng_uniform(&rng);
+        int reflectFromSurface =
+            (doSpecular && rouletteRandomFloat < fresnel_reflection(bestNormal, incident,
+                                                                    incidentMedium.refractiveIndex,
+                                                                    transmittedMedium.refractiveIndex,
+                                                                    transmissionDirection));
+        (void)reflectionDirection;
+        if (reflectFromSurface) {
+            *notAbsorbed = mul3(*notAbsorbed, bestMaterial.specularColor);
+            ray->origin = add3(bestIntersectionPoint, biasVector);
+            ray->direction = reflectionDirection;
+        } else if (bestMaterial.hasTransmission) {
+            *medium = transmittedMedium.absorptionAndScatteringProperties;
+            ray->origin = sub3(bestIntersectionPoint, biasVector);
+            ray->direction = transmissionDirection;
+        } else {
+            *accumulated = add3(*accumulated, mul3(*notAbsorbed, bestMaterial.emittedColor));
+            *notAbsorbed = mul3(*notAbsorbed, bestMaterial.diffuseColor);
+            float randomFloat1 = rng_uniform(&rng);
+            float randomFloat2 = rng_uniform(&rng);
+            ray->origin = add3(bestIntersectionPoint, biasVector);
+            ray->direction = cosine_weighted_direction(bestNormal, randomFloat1, randomFloat2);
+        }
+        if (length3(*notAbsorbed) <= P->min_ray_weight) return 0;
+        return 1;
+    } else {
+        *accumulated = add3(*accumulated, mul3(*notAbsorbed, background_color(currentRay.direction)));
+        return 0;
+    }
+}
+
+/* ---- launchKernel (:760-882) over a list of pixels ------------------------
+ * pixel_ids == NULL: every pixel 0..numPixels-1 (the reference's behaviour).
+ * Otherwise only the listed pixels are rendered (each pixel of a pass is
+ * independent of every other, so a subset gives the same values as the full
+ * pass does for those pixels).
+ * out_rgb:   n x 3, this pass's radiance (the D2H copy of :869).
+ * live_at_depth (may be NULL): max_depth entries, number of live paths that
+ *            enter each depth (numActivePixels at each traceRayKernel launch).
+ * first_hit (may be NULL): n entries, closest hit of the primary rays.
+ * Returns sum over depths of live paths (path-bounces of this pass). */
+int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
+                        int numPixels, const int32_t* pixel_ids, int n,
+                        int counter, const Camera* camera, const orc_params* P,
+                        float* out_rgb, int64_t* live_at_depth, orc_hit* first_hit) {
+    if (!pixel_ids) n = numPixels;
+    int* activePixels = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    Ray* rays = (Ray*)malloc(sizeof(Ray) * (size_t)(n > 0 ? n : 1));
+    AbsorptionAndScatteringProperties* mediums =
+        (AbsorptionAndScatteringProperties*)malloc(sizeof(*mediums) * (size_t)(n > 0 ? n : 1));
+    f3* notAbsorbed = (f3*)malloc(sizeof(f3) * (size_t)(n > 0 ? n : 1));
+    f3* accumulated = (f3*)malloc(sizeof(f3) * (size_t)(n > 0 ? n : 1));
+    uint32_t seed = (uint32_t)counter;
+
+    /* initializeThings (:86-102) + raycastFromCameraKernel (:794). Slot k holds pixel id(k). */
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < n; k++) {
+        int pix = pixel_ids ? pixel_ids[k] : k;
+        activePixels[k] = k;
+        set_air_as(&mediums[k]);
+        notAbsorbed[k] = mk3(1, 1, 1);
+        accumulated[k] = mk3(0, 0, 0);
+        raycast_pixel(*camera, pix, seed, P, &rays[k]);
+    }
+
+    int numActive = n;
+    int64_t total = 0;
+    for (int rayDepth = 0; rayDepth < P->max_depth; rayDepth++) {
+        if (live_at_depth) live_at_depth[rayDepth] = numActive;
+        total += numActive;
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int a = 0; a < numActive; a++) {
+            int k = activePixels[a];
+            int pix = pixel_ids ? pixel_ids[k] : k;
+            orc_hit* h = (first_hit && rayDepth == 0) ? &first_hit[k] : NULL;
+            int alive = trace_path(numPolys, polys, numSpheres, spheres, pix, rayDepth, seed, P,
+                                   &rays[k], &mediums[k], &notAbsorbed[k], &accumulated[k], h);
+            if (!alive) activePixels[a] = -1;
+        }
+        /* thrust::remove_if(..., isNegative()) (:811-813, :731-738): stable */
+        int w = 0;
+        for (int a = 0; a < numActive; a++)
+            if (!(activePixels[a] < 0)) activePixels[w++] = activePixels[a];
+        numActive = w;
+    }
+    for (int k = 0; k < n; k++) {
+        out_rgb[3 * k + 0] = accumulated[k].x;
+        out_rgb[3 * k + 1] = accumulated[k].y;
+        out_rgb[3 * k + 2] = accumulated[k].z;
+    }
+    free(activePixels); free(rays); free(mediums); free(notAbsorbed); free(accumulated);
+    return total;
+}
+
+/* Primary rays only (raycastFromCameraKernel), n x 6 floats origin,direction. */
+void orc_camera_rays(int numPixels, const int32_t* pixel_ids, int n, int counter,
+                     const Camera* camera, const orc_params* P, float* out_rays) {
+    if (!pixel_ids) n = numPixels;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < n; k++) {
+        Ray r;
+        raycast_pixel(*camera, pixel_ids ? pixel_ids[k] : k, (uint32_t)counter, P, &r);
+        memcpy(out_rays + 6 * (size_t)k, &r, sizeof(r));
+    }
+}
+
+/* The reference's triangle loop (:536-557) alone, for arbitrary rays:
+ * verts n_tris x 9 floats (p0,p1,p2), rays n x 6; tri = -1 on a miss;
+ * t_init is the bestT the loop starts from (123456789 in the reference). */
+void orc_closest_triangle(const float* verts, int n_tris, const float* rays, int n,
+                          float t_init, int32_t* tri, float* t_out) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int k = 0; k < n; k++) {
+        f3 o = mk3(rays[6 * k], rays[6 * k + 1], rays[6 * k + 2]);
+        f3 d = mk3(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]);
+        float bestT = t_init;
+        int best = -1;
+        for (int i = 0; i < n_tris; i++) {
+            const float* v = verts + 9 * (size_t)i;
+            float pt, b1, b2;
+            if (triangle_intersect(mk3(v[0], v[1], v[2]), mk3(v[3], v[4], v[5]), mk3(v[6], v[7], v[8]),
+                                   o, d, &pt, &b1, &b2)) {
+                if (pt > 0 && pt < bestT) { bestT = pt; best = i; }
+            }
+        }
+        tri[k] = best;
+        t_out[k] = bestT;
+    }
+}
+
+/* ---- floatTo8Bit(c / passCounter) (color.cpp:41-62, display.cpp:198,
+ *      BasicMath::clamp basic_math.cpp:58-78) ------------------------------ */
+static float bm_min(float a, float b) { if (a < b) return a; else return b; }
+static float bm_max(float a, float b) { if (a > b) return a; else return b; }
+static float bm_clamp(float n, float low, float high) { n = bm_min(n, high); n = bm_max(n, low); return n; }
+void orc_tonemap_8bit(const float* sum_rgb, int numPixels, int passes, unsigned char* out) {
+    float gamma = (float)2.2;
+    float oneOverGamma = (float)(1.0 / gamma);
+    for (int i = 0; i < numPixels * 3; i++) {
+        float c = sum_rgb[i] / (float)passes;          /* float3 / int -> float divide */
+        float g = powf(c, oneOverGamma);               /* std::pow(float,float) */
+        out[i] = (unsigned char)bm_clamp(g * 255, 0, 255);
+    }
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

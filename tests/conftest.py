@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def reference_root():
+    """The read-only reference checkout; absent on the GPU box."""
+    p = "/root/reference/GPUPathTracer"
+    if not os.path.isdir(p):
+        pytest.skip("reference checkout not present")
+    return p
