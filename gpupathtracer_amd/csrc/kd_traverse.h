@@ -1,0 +1,162 @@
+// kd_traverse.h -- closest-triangle query through the flattened kd-tree.
+//
+// The result is defined by the reference's brute-force loop
+// (path_tracer_kernel.cu:536-557): among all triangles whose Moller-Trumbore
+// test (:226-248) reports a hit with 0 < t < t_limit, the smallest t; equal t
+// goes to the lowest triangle index (the loop's strict '<').  Traversal may
+// only skip triangles that cannot win, so every interval decision below is
+// taken against split planes thickened by a spatial slack `sigma` (and a small
+// relative slack on t): a node is skipped only when the ray misses it by more
+// than any rounding error of the plane distances or of the triangle test.
+//
+// Traversal order follows the classic kd scheme (design source:
+// cukd/detail/kdtree_kernels.cu:50-170): descend towards the side of the
+// origin, defer the far child with its [tmin,tmax], stop as soon as the best
+// hit lies in front of every deferred interval.
+#pragma once
+#include "pt_device.h"
+
+namespace pt {
+
+struct KdNode { uint32_t w0, w1; };
+
+// Triangle record: a, edge1 = b - a, edge2 = c - a packed in three 16-byte
+// words: (a.x a.y a.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z - - -).
+struct TriRec { float f[12]; };
+
+struct KdView {
+    const KdNode* nodes;
+    const int32_t* refs;
+    const TriRec* tris;
+    float bmin[3], bmax[3];
+    float sigma;       // spatial slack: 2e-5 * largest extent of the root box
+};
+
+#define PT_KD_REL_SLACK 4e-6f
+
+PT_HD float sel3(int axis, float x, float y, float z) { return axis == 0 ? x : (axis == 1 ? y : z); }
+
+PT_HD float bits_to_float(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; __builtin_memcpy(&f, &u, 4); return f;
+#endif
+}
+
+PT_HD void load_tri(const TriRec* tris, int idx, V3& a, V3& e1, V3& e2) {
+    const float* f = tris[idx].f;
+    a = v3(f[0], f[1], f[2]);
+    e1 = v3(f[3], f[4], f[5]);
+    e2 = v3(f[6], f[7], f[8]);
+}
+
+// Stack concept: void reset(); void push(uint32_t node, float tmin, float tmax);
+//                bool pop(uint32_t& node, float& tmin, float& tmax);
+template <class Stack, bool STATS>
+PT_HD void kd_closest_hit(const KdView& kd, V3 o, V3 d, float& bestT, int& bestTri, Stack& st,
+                          uint32_t& nodesVisited, uint32_t& trisTested) {
+    // ---- clip against the (padded) root box ----
+    float tmin = 0.0f, tmax = bestT;
+    {
+        const float oc[3] = {o.x, o.y, o.z};
+        const float dc[3] = {d.x, d.y, d.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
+            if (dc[a] != 0.0f) {
+                float inv = 1.0f / dc[a];
+                float ta = (lo - oc[a]) * inv, tb = (hi - oc[a]) * inv;
+                float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+                tn -= PT_KD_REL_SLACK * fabsf(tn);
+                tf += PT_KD_REL_SLACK * fabsf(tf);
+                tmin = fmaxf(tmin, tn);
+                tmax = fminf(tmax, tf);
+            } else if (!(oc[a] >= lo && oc[a] <= hi)) {
+                return;
+            }
+        }
+        if (!(tmin <= tmax)) return;
+    }
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t node = 0;
+    st.reset();
+
+    for (;;) {
+        KdNode w = kd.nodes[node];
+        if (STATS) nodesVisited++;
+        while ((w.w0 & 3u) != 3u) {
+            const int axis = (int)(w.w0 & 3u);
+            const float split = bits_to_float(w.w1);
+            const uint32_t left = w.w0 >> 2;
+            const float oa = sel3(axis, o.x, o.y, o.z);
+            const float da = sel3(axis, d.x, d.y, d.z);
+            const float ia = sel3(axis, inv.x, inv.y, inv.z);
+            const bool leftFirst = (oa < split) || (oa == split && da <= 0.0f);
+            const uint32_t nearC = leftFirst ? left : left + 1u;
+            const uint32_t farC = leftFirst ? left + 1u : left;
+            if (da == 0.0f) {
+                // parallel to the plane: one side, or both when inside the slab
+                if (fabsf(oa - split) <= kd.sigma) st.push(farC, tmin, tmax);
+                node = nearC;
+            } else {
+                const float tp = (split - oa) * ia;
+                const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
+                const float lo = tp - s, hi = tp + s;
+                if (lo > tmax || hi < 0.0f) {
+                    node = nearC;                 // plane beyond the interval or behind the origin
+                } else if (lo < 0.0f) {
+                    // origin inside the thickened plane: the crossing may be real or lie
+                    // behind the origin, so either side can own the whole interval
+                    st.push(farC, tmin, tmax);
+                    node = nearC;
+                } else if (hi < tmin) {
+                    node = farC;                  // plane crossed before the interval starts
+                } else {
+                    st.push(farC, fmaxf(tmin, lo), tmax);
+                    node = nearC;
+                    tmax = fminf(tmax, hi);
+                }
+            }
+            w = kd.nodes[node];
+            if (STATS) nodesVisited++;
+        }
+        // ---- leaf ----
+        const uint32_t first = w.w0 >> 2, count = w.w1;
+        for (uint32_t k = 0; k < count; k++) {
+            const int idx = kd.refs[first + k];
+            V3 a, e1, e2;
+            load_tri(kd.tris, idx, a, e1, e2);
+            float t;
+            if (STATS) trisTested++;
+            if (triangle_t(a, e1, e2, o, d, t)) {
+                if (t > 0.0f && (t < bestT || (t == bestT && bestTri >= 0 && idx < bestTri))) {
+                    bestT = t;
+                    bestTri = idx;
+                }
+            }
+        }
+        // ---- next deferred interval that can still hold a closer (or equal) hit ----
+        do {
+            if (!st.pop(node, tmin, tmax)) return;
+        } while (bestT < tmin);
+        tmax = fminf(tmax, bestT);
+    }
+}
+
+// The reference's loop itself (:536-557) over the same triangle records.
+template <bool STATS>
+PT_HD void brute_closest_hit(const TriRec* tris, int n, V3 o, V3 d, float& bestT, int& bestTri,
+                             uint32_t& trisTested) {
+    for (int i = 0; i < n; i++) {
+        V3 a, e1, e2;
+        load_tri(tris, i, a, e1, e2);
+        float t;
+        if (triangle_t(a, e1, e2, o, d, t)) {
+            if (t > 0 && t < bestT) { bestT = t; bestTri = i; }
+        }
+    }
+    if (STATS) trisTested += (uint32_t)n;
+}
+
+}  // namespace pt

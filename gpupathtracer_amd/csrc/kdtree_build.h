@@ -1,0 +1,27 @@
+// kdtree_build.h -- host kd-tree builder interface (plain C++).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace gptkd {
+
+struct Node { uint32_t w0, w1; };
+
+struct BuildParams {
+    int   small_threshold = 64;   // <= this many triangles: SAH stage (cukd/kdtree.cu:76)
+    float traversal_cost = 6.0f;  // constant term of the SAH cost (small_node_array_kernels.cu:78-79)
+};
+
+struct Tree {
+    std::vector<Node> nodes;      // inner: w0 = left<<2 | axis, w1 = split bits; leaf: w0 = first_ref<<2 | 3, w1 = count
+    std::vector<int32_t> refs;    // triangle indices, leaf by leaf
+    float bounds[6];              // root box: min xyz, max xyz
+    int max_depth;
+    int n_leaves;
+    int n_empty_leaves;
+};
+
+// verts: n_tris x 9 floats (p0, p1, p2).
+void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out);
+
+}  // namespace gptkd

@@ -61,9 +61,9 @@ CAMERA_DTYPE = np.dtype({
 RENDER_PARAMS_DTYPE = np.dtype({
     "names": ["max_depth", "ray_bias", "min_ray_weight", "ground_elevation", "ground_enabled",
               "row_stride_is_width", "use_kdtree", "kd_small_threshold", "reserved"],
-    "formats": [np.int32, np.float32, np.float32, np.float32, np.int32, np.int32, np.int32,
-                np.int32, (np.int32, (8,))],
-    "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32],
+    "formats": [np.int32, np.float32, np.float64, np.float32, np.int32, np.int32, np.int32,
+                np.int32, (np.int32, (7,))],
+    "offsets": [0, 4, 8, 16, 20, 24, 28, 32, 36],
     "itemsize": 64,
 })
 

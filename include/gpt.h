@@ -150,20 +150,20 @@ const char* gpt_last_error(void);
 /* those values except max_depth, which callers normally lower.               */
 /* ------------------------------------------------------------------------- */
 typedef struct gpt_render_params {
-    int   max_depth;          /* MAX_TRACE_DEPTH, 30                    (:47)  */
-    float ray_bias;           /* RAY_BIAS_DISTANCE, 0.0002f             (:48)  */
-    float min_ray_weight;     /* MIN_RAY_WEIGHT, 0.00001f  (compared in double)*/
-    float ground_elevation;   /* HARD_CODED_GROUND_ELEVATION, -0.8f     (:50)  */
-    int   ground_enabled;     /* 1: the infinite ground plane exists (as :510) */
+    int    max_depth;         /* MAX_TRACE_DEPTH, 30                    (:47)  */
+    float  ray_bias;          /* RAY_BIAS_DISTANCE, 0.0002 narrowed to float at its use (:48,:659) */
+    double min_ray_weight;    /* MIN_RAY_WEIGHT, 0.00001, compared in double (:49,:583,:705) */
+    float  ground_elevation;  /* HARD_CODED_GROUND_ELEVATION, -0.8f     (:50)  */
+    int    ground_enabled;    /* 1: the infinite ground plane exists (as :510) */
     /* Pixel -> (x,y).  0: the reference's arithmetic, row stride =
      * resolution.y (:135-136; only right for square images).  1: row stride =
      * resolution.x (right for any image).  Identical for square images.       */
-    int   row_stride_is_width;
+    int    row_stride_is_width;
     /* 0: brute-force loop over every triangle, as the reference (:536-557).
      * 1: kd-tree traversal returning the same hit as that loop.               */
-    int   use_kdtree;
-    int   kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64)  */
-    int   reserved[8];
+    int    use_kdtree;
+    int    kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64) */
+    int    reserved[7];
 } gpt_render_params;
 
 void gpt_render_params_default(gpt_render_params* p);
