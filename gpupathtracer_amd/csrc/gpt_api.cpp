@@ -1,0 +1,717 @@
+// gpt_api.cpp -- host side of the C-ABI declared in include/gpt.h: scene upload,
+// pass orchestration on one HIP stream, statistics, and the reference-compatible
+// launchKernel entry point (path_tracer_kernel.cu:760-882).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gpt.h"
+#include "gpt_device_structs.h"
+#include "kd_traverse.h"
+#include "kdtree_build.h"
+#include "pt_device.h"
+
+using pt::CamPre;
+using pt::ShadeParams;
+using pt::TriRec;
+
+// kernels (gpt_kernels.hip)
+extern "C" {
+void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, uint32_t seed, float4* ray_o,
+                 float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts);
+void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
+                    const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
+                    unsigned long long* stats, uint32_t* spill, size_t spill_stride);
+void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed,
+                const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+                float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work);
+void gptk_finish(hipStream_t s, int grid, int numPixels, const float4* pass_rgb, float4* image, float* pass_out3);
+void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
+                          int32_t* tri, float* t_out, uint32_t* spill, size_t spill_stride);
+void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
+}
+
+namespace {
+
+thread_local std::string g_error;
+
+gpt_status fail(gpt_status st, const std::string& msg) {
+    g_error = msg;
+    return st;
+}
+
+#define HIP_TRY(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char buf_[512];                                                                   \
+            snprintf(buf_, sizeof(buf_), "HIP error in file '%s' in line %i : %s.", __FILE__, \
+                     __LINE__, hipGetErrorString(e_));                                        \
+            return fail(GPT_ERR_HIP, buf_);                                                   \
+        }                                                                                     \
+    } while (0)
+
+const int kBlock = 256;
+const int kTraceGrid = 2048;        // persistent grid of the intersect / shade kernels
+
+struct MatKey {
+    uint32_t w[15];
+    bool operator<(const MatKey& o) const { return memcmp(w, o.w, sizeof(w)) < 0; }
+};
+
+MatKey mat_key(const Material& m) {
+    MatKey k;
+    memset(&k, 0, sizeof(k));
+    memcpy(&k.w[0], &m.diffuseColor, 12);
+    memcpy(&k.w[3], &m.emittedColor, 12);
+    memcpy(&k.w[6], &m.specularColor, 12);
+    k.w[9] = m.hasTransmission ? 1u : 0u;
+    memcpy(&k.w[10], &m.medium, 20);
+    return k;
+}
+
+struct MatTable {
+    std::map<MatKey, int> index;
+    std::vector<float> packed;   // 16 floats per material
+    int add(const Material& m) {
+        MatKey k = mat_key(m);
+        auto it = index.find(k);
+        if (it != index.end()) return it->second;
+        int id = (int)index.size();
+        index[k] = id;
+        const AbsorptionAndScatteringProperties& as = m.medium.absorptionAndScatteringProperties;
+        const float rec[16] = {
+            m.diffuseColor.x, m.diffuseColor.y, m.diffuseColor.z, m.medium.refractiveIndex,
+            m.specularColor.x, m.specularColor.y, m.specularColor.z, m.hasTransmission ? 1.0f : 0.0f,
+            m.emittedColor.x, m.emittedColor.y, m.emittedColor.z, as.reducedScatteringCoefficient,
+            as.absorptionCoefficient.x, as.absorptionCoefficient.y, as.absorptionCoefficient.z, 0.0f};
+        packed.insert(packed.end(), rec, rec + 16);
+        return id;
+    }
+};
+
+template <class T>
+gpt_status upload(T** dst, const void* src, size_t bytes) {
+    *dst = nullptr;
+    HIP_TRY(hipMalloc((void**)dst, bytes > 0 ? bytes : 16));
+    if (bytes > 0) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+
+}  // namespace
+
+struct gpt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    gpt_render_params params;
+
+    // geometry
+    float4* d_spheres = nullptr;
+    int* d_sphere_mat = nullptr;
+    TriRec* d_tris = nullptr;
+    float4* d_tri_nm = nullptr;
+    float4* d_mats = nullptr;
+    pt::KdNode* d_nodes = nullptr;
+    int32_t* d_refs = nullptr;
+    uint32_t* d_spill = nullptr;
+    size_t spill_stride = 0;
+    DevGeometry geom;
+    int n_nodes = 0, n_refs = 0, tree_depth = 0;
+
+    // per-pixel / per-path buffers
+    int numPixels = 0;
+    float4* d_ray_o[2] = {nullptr, nullptr};
+    float4* d_ray_d[2] = {nullptr, nullptr};
+    float4* d_thr[2] = {nullptr, nullptr};
+    float2* d_hit = nullptr;
+    float4* d_pass = nullptr;
+    float4* d_image = nullptr;
+    float* d_pass3 = nullptr;
+    unsigned* d_counters = nullptr;          // GPT_COUNTER_WORDS
+    unsigned long long* d_stats = nullptr;   // GPT_STAT_WORDS
+    uint64_t passes = 0;
+
+    // timing
+    bool profile = false;
+    bool kd_stats = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, size_t>> trace_pairs;   // indices into ev_pool
+    std::vector<std::pair<size_t, size_t>> total_pairs;
+    double ms_trace = 0, ms_total = 0;
+    uint64_t trace_launches = 0;
+};
+
+namespace {
+
+gpt_status free_pixel_buffers(gpt_scene* s) {
+    for (int k = 0; k < 2; k++) {
+        if (s->d_ray_o[k]) HIP_TRY(hipFree(s->d_ray_o[k]));
+        if (s->d_ray_d[k]) HIP_TRY(hipFree(s->d_ray_d[k]));
+        if (s->d_thr[k]) HIP_TRY(hipFree(s->d_thr[k]));
+        s->d_ray_o[k] = s->d_ray_d[k] = s->d_thr[k] = nullptr;
+    }
+    if (s->d_hit) HIP_TRY(hipFree(s->d_hit));
+    if (s->d_pass) HIP_TRY(hipFree(s->d_pass));
+    if (s->d_image) HIP_TRY(hipFree(s->d_image));
+    if (s->d_pass3) HIP_TRY(hipFree(s->d_pass3));
+    s->d_hit = nullptr; s->d_pass = nullptr; s->d_image = nullptr; s->d_pass3 = nullptr;
+    s->numPixels = 0;
+    return GPT_OK;
+}
+
+gpt_status get_event(gpt_scene* s, size_t* idx) {
+    if (s->ev_used == s->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev_pool.push_back(e);
+    }
+    *idx = s->ev_used++;
+    return GPT_OK;
+}
+
+// Fold finished event pairs into the running totals.  Requires a synchronised stream.
+gpt_status collect_events(gpt_scene* s) {
+    for (auto& p : s->trace_pairs) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[p.first], s->ev_pool[p.second]));
+        s->ms_trace += ms;
+        s->trace_launches++;
+    }
+    for (auto& p : s->total_pairs) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[p.first], s->ev_pool[p.second]));
+        s->ms_total += ms;
+    }
+    s->trace_pairs.clear();
+    s->total_pairs.clear();
+    s->ev_used = 0;
+    return GPT_OK;
+}
+
+CamPre make_cam(const Camera* c, int row_stride_is_width) {
+    return pt::camera_precompute(pt::v3(c->position.x, c->position.y, c->position.z),
+                                 pt::v3(c->view.x, c->view.y, c->view.z), pt::v3(c->up.x, c->up.y, c->up.z),
+                                 c->resolution.x, c->resolution.y, c->fov.x, c->fov.y, c->apertureRadius,
+                                 c->focalDistance, row_stride_is_width);
+}
+
+int pixel_grid(int numPixels) {
+    int g = (numPixels + kBlock - 1) / kBlock;
+    return std::max(1, std::min(g, 4096));
+}
+
+// Enqueue one pass.  pass3: optional device buffer receiving this pass as packed float3.
+gpt_status enqueue_pass(gpt_scene* s, const Camera* cam, int counter, float* pass3) {
+    const int N = s->numPixels;
+    const uint32_t seed = (uint32_t)counter;
+    const CamPre cp = make_cam(cam, s->params.row_stride_is_width);
+    ShadeParams sp;
+    sp.ray_bias = s->params.ray_bias;
+    sp.min_ray_weight = s->params.min_ray_weight;
+    unsigned* counts = s->d_counters;
+    unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
+    const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
+
+    size_t e0 = 0, e1 = 0;
+    if (s->profile) { gpt_status st = get_event(s, &e0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[e0], s->stream)); }
+
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
+    gptk_camera(s->stream, pixel_grid(N), &cp, N, seed, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_pass, counts);
+    const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
+    for (int depth = 0; depth < s->params.max_depth; depth++) {
+        const int in = depth & 1, out = in ^ 1;
+        size_t t0 = 0, t1 = 0;
+        if (s->profile) { gpt_status st = get_event(s, &t0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[t0], s->stream)); }
+        gptk_intersect(s->stream, grid, &s->geom, use_kd, s->kd_stats ? 1 : 0, depth, s->d_ray_o[in], s->d_ray_d[in],
+                       s->d_hit, counts, work, s->d_stats, s->d_spill, s->spill_stride);
+        if (s->profile) {
+            gpt_status st = get_event(s, &t1); if (st) return st;
+            HIP_TRY(hipEventRecord(s->ev_pool[t1], s->stream));
+            s->trace_pairs.push_back({t0, t1});
+        }
+        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in], s->d_hit,
+                   s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
+    }
+    gptk_finish(s->stream, pixel_grid(N), N, s->d_pass, s->d_image, pass3);
+    HIP_TRY(hipGetLastError());
+    if (s->profile) {
+        gpt_status st = get_event(s, &e1); if (st) return st;
+        HIP_TRY(hipEventRecord(s->ev_pool[e1], s->stream));
+        s->total_pairs.push_back({e0, e1});
+    }
+    s->passes++;
+    return GPT_OK;
+}
+
+gpt_status check_render_args(gpt_scene* s, const Camera* cam) {
+    if (!s || !cam) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene or camera");
+    const long long w = (long long)cam->resolution.x, h = (long long)cam->resolution.y;
+    if (w <= 0 || h <= 0 || w * h != (long long)s->numPixels)
+        return fail(GPT_ERR_INVALID_ARGUMENT,
+                    "camera resolution does not match the pixel count given to gpt_scene_reset");
+    return GPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gpt_last_error(void) { return g_error.c_str(); }
+void gpt_set_last_error_(const char* msg) { g_error = msg ? msg : ""; }
+
+void gpt_render_params_default(gpt_render_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->max_depth = 30;
+    p->ray_bias = (float)0.0002;
+    p->min_ray_weight = 0.00001;
+    p->ground_elevation = (float)-0.8;
+    p->ground_enabled = 1;
+    p->row_stride_is_width = 1;
+    p->use_kdtree = 1;
+    p->kd_small_threshold = 64;
+}
+
+gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* polys, int numPolys,
+                            const gpt_render_params* params, int device, gpt_scene** out_scene) {
+    if (!out_scene) return fail(GPT_ERR_INVALID_ARGUMENT, "out_scene is null");
+    *out_scene = nullptr;
+    if (numSpheres < 0 || numPolys < 0 || (numSpheres > 0 && !spheres) || (numPolys > 0 && !polys))
+        return fail(GPT_ERR_INVALID_ARGUMENT, "bad sphere/poly arrays");
+    if (numSpheres >= 0x40000000 || numPolys >= 0x40000000)
+        return fail(GPT_ERR_TOO_LARGE, "too many primitives");
+    gpt_render_params rp;
+    if (params) rp = *params; else gpt_render_params_default(&rp);
+    if (rp.max_depth < 0 || rp.max_depth > GPT_MAX_DEPTH)
+        return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
+    if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 64;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GPT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(GPT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    gpt_scene* s = new gpt_scene();
+    s->device = device;
+    s->params = rp;
+    gpt_status st = GPT_OK;
+    do {
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+            st = fail(GPT_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        MatTable mt;
+        std::vector<float> sph((size_t)numSpheres * 4);
+        std::vector<int> sph_mat((size_t)numSpheres);
+        for (int i = 0; i < numSpheres; i++) {
+            sph[4 * (size_t)i + 0] = spheres[i].position.x;
+            sph[4 * (size_t)i + 1] = spheres[i].position.y;
+            sph[4 * (size_t)i + 2] = spheres[i].position.z;
+            sph[4 * (size_t)i + 3] = spheres[i].radius;
+            sph_mat[(size_t)i] = mt.add(spheres[i].material);
+        }
+        std::vector<TriRec> recs((size_t)numPolys);
+        std::vector<float> nm((size_t)numPolys * 4);
+        std::vector<float> verts((size_t)numPolys * 9);
+        for (int i = 0; i < numPolys; i++) {
+            const Poly& p = polys[i];
+            float* f = recs[(size_t)i].f;
+            f[0] = p.p0.x; f[1] = p.p0.y; f[2] = p.p0.z;
+            f[3] = p.p1.x - p.p0.x; f[4] = p.p1.y - p.p0.y; f[5] = p.p1.z - p.p0.z;   // edge1 (:230)
+            f[6] = p.p2.x - p.p0.x; f[7] = p.p2.y - p.p0.y; f[8] = p.p2.z - p.p0.z;   // edge2 (:231)
+            f[9] = f[10] = f[11] = 0.0f;
+            float* v = &verts[9 * (size_t)i];
+            v[0] = p.p0.x; v[1] = p.p0.y; v[2] = p.p0.z;
+            v[3] = p.p1.x; v[4] = p.p1.y; v[5] = p.p1.z;
+            v[6] = p.p2.x; v[7] = p.p2.y; v[8] = p.p2.z;
+            nm[4 * (size_t)i + 0] = p.n.x; nm[4 * (size_t)i + 1] = p.n.y; nm[4 * (size_t)i + 2] = p.n.z;
+            int id = mt.add(p.material);
+            memcpy(&nm[4 * (size_t)i + 3], &id, 4);
+        }
+        gptkd::Tree tree;
+        gptkd::BuildParams bp;
+        bp.small_threshold = rp.kd_small_threshold;
+        gptkd::build(verts.data(), numPolys, bp, tree);
+        s->n_nodes = (int)tree.nodes.size();
+        s->n_refs = (int)tree.refs.size();
+        s->tree_depth = tree.max_depth;
+
+        if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
+        if ((st = upload(&s->d_sphere_mat, sph_mat.data(), sph_mat.size() * 4))) break;
+        if ((st = upload(&s->d_tris, recs.data(), recs.size() * sizeof(TriRec)))) break;
+        if ((st = upload(&s->d_tri_nm, nm.data(), nm.size() * 4))) break;
+        if ((st = upload(&s->d_mats, mt.packed.data(), mt.packed.size() * 4))) break;
+        if ((st = upload(&s->d_nodes, tree.nodes.data(), tree.nodes.size() * 8))) break;
+        if ((st = upload(&s->d_refs, tree.refs.data(), tree.refs.size() * 4))) break;
+
+        s->spill_stride = (size_t)kTraceGrid * kBlock;
+        const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
+        if (hipMalloc((void**)&s->d_spill, spill_words * 4) != hipSuccess) { st = fail(GPT_ERR_OUT_OF_MEMORY, "spill buffer"); break; }
+        if (hipMalloc((void**)&s->d_counters, sizeof(unsigned) * GPT_COUNTER_WORDS) != hipSuccess ||
+            hipMalloc((void**)&s->d_stats, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) {
+            st = fail(GPT_ERR_OUT_OF_MEMORY, "counters");
+            break;
+        }
+        if (hipMemset(s->d_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) { st = fail(GPT_ERR_HIP, "memset"); break; }
+
+        DevGeometry& g = s->geom;
+        g.spheres = s->d_spheres;
+        g.sphere_mat = s->d_sphere_mat;
+        g.n_spheres = numSpheres;
+        g.n_tris = numPolys;
+        g.tri_nm = s->d_tri_nm;
+        g.mats = s->d_mats;
+        g.kd.nodes = s->d_nodes;
+        g.kd.refs = s->d_refs;
+        g.kd.tris = s->d_tris;
+        float ext = 0;
+        for (int k = 0; k < 3; k++) {
+            g.kd.bmin[k] = tree.bounds[k];
+            g.kd.bmax[k] = tree.bounds[3 + k];
+            ext = std::max(ext, tree.bounds[3 + k] - tree.bounds[k]);
+        }
+        g.kd.sigma = 2e-5f * ext;
+        g.ground_elevation = rp.ground_elevation;
+        g.ground_enabled = rp.ground_enabled;
+    } while (0);
+    if (st != GPT_OK) {
+        std::string keep = g_error;
+        gpt_scene_destroy(s);
+        g_error = keep;
+        return st;
+    }
+    *out_scene = s;
+    return GPT_OK;
+}
+
+gpt_status gpt_scene_destroy(gpt_scene* s) {
+    if (!s) return GPT_OK;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    free_pixel_buffers(s);
+    void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_tri_nm, s->d_mats, s->d_nodes,
+                    s->d_refs, s->d_spill, s->d_counters, s->d_stats};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return GPT_OK;
+}
+
+gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
+    if (!s || numPixels <= 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad scene or pixel count");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    gpt_status st = collect_events(s);
+    if (st) return st;
+    if (numPixels != s->numPixels) {
+        if ((st = free_pixel_buffers(s))) return st;
+        const size_t n = (size_t)numPixels;
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc((void**)&s->d_ray_o[k], n * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&s->d_ray_d[k], n * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&s->d_thr[k], n * sizeof(float4)));
+        }
+        HIP_TRY(hipMalloc((void**)&s->d_hit, n * sizeof(float2)));
+        HIP_TRY(hipMalloc((void**)&s->d_pass, n * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&s->d_image, n * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&s->d_pass3, n * 3 * sizeof(float)));
+        s->numPixels = numPixels;
+    }
+    HIP_TRY(hipMemsetAsync(s->d_image, 0, (size_t)numPixels * sizeof(float4), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->passes = 0;
+    s->ms_trace = s->ms_total = 0;
+    s->trace_launches = 0;
+    return GPT_OK;
+}
+
+gpt_status gpt_render_pass(gpt_scene* s, const Camera* cam, int counter, float* host_pixels) {
+    gpt_status st = check_render_args(s, cam);
+    if (st) return st;
+    HIP_TRY(hipSetDevice(s->device));
+    if ((st = enqueue_pass(s, cam, counter, host_pixels ? s->d_pass3 : nullptr))) return st;
+    if (host_pixels) {
+        HIP_TRY(hipMemcpyAsync(host_pixels, s->d_pass3, (size_t)s->numPixels * 3 * sizeof(float),
+                               hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return collect_events(s);
+}
+
+gpt_status gpt_render_range(gpt_scene* s, const Camera* cam, int counter_begin, int counter_end, int sync) {
+    gpt_status st = check_render_args(s, cam);
+    if (st) return st;
+    HIP_TRY(hipSetDevice(s->device));
+    for (int c = counter_begin; c < counter_end; c++) {
+        if ((st = enqueue_pass(s, cam, c, nullptr))) return st;
+        if (s->profile && s->ev_used > 8192) {
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            if ((st = collect_events(s))) return st;
+        }
+    }
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return collect_events(s);
+    }
+    return GPT_OK;
+}
+
+gpt_status gpt_scene_sync(gpt_scene* s) {
+    if (!s) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return collect_events(s);
+}
+
+gpt_status gpt_scene_set_profiling(gpt_scene* s, int time_kernels, int count_kd_work) {
+    if (!s) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene");
+    gpt_status st = gpt_scene_sync(s);
+    if (st) return st;
+    s->profile = time_kernels != 0;
+    s->kd_stats = count_kd_work != 0;
+    return GPT_OK;
+}
+
+gpt_status gpt_accum_device_ptr(gpt_scene* s, void** out_ptr, size_t* out_bytes) {
+    if (!s || !out_ptr || !s->d_image) return fail(GPT_ERR_INVALID_ARGUMENT, "no image (call gpt_scene_reset first)");
+    *out_ptr = s->d_image;
+    if (out_bytes) *out_bytes = (size_t)s->numPixels * sizeof(float4);
+    return GPT_OK;
+}
+
+gpt_status gpt_accum_download(gpt_scene* s, float* host_rgb, int* out_passes) {
+    if (!s || !s->d_image || !host_rgb) return fail(GPT_ERR_INVALID_ARGUMENT, "no image or null output");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<float> tmp((size_t)s->numPixels * 4);
+    HIP_TRY(hipMemcpy(tmp.data(), s->d_image, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < (size_t)s->numPixels; i++) {
+        host_rgb[3 * i + 0] = tmp[4 * i + 0];
+        host_rgb[3 * i + 1] = tmp[4 * i + 1];
+        host_rgb[3 * i + 2] = tmp[4 * i + 2];
+    }
+    if (out_passes) *out_passes = s->numPixels > 0 ? (int)tmp[3] : 0;
+    return collect_events(s);
+}
+
+gpt_status gpt_accum_upload(gpt_scene* s, const float* host_rgb, int passes) {
+    if (!s || !s->d_image || !host_rgb) return fail(GPT_ERR_INVALID_ARGUMENT, "no image or null input");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<float> tmp((size_t)s->numPixels * 4);
+    for (size_t i = 0; i < (size_t)s->numPixels; i++) {
+        tmp[4 * i + 0] = host_rgb[3 * i + 0];
+        tmp[4 * i + 1] = host_rgb[3 * i + 1];
+        tmp[4 * i + 2] = host_rgb[3 * i + 2];
+        tmp[4 * i + 3] = (float)passes;
+    }
+    HIP_TRY(hipMemcpy(s->d_image, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+
+gpt_status gpt_get_stats(gpt_scene* s, gpt_stats* out) {
+    if (!s || !out) return fail(GPT_ERR_INVALID_ARGUMENT, "null argument");
+    gpt_status st = gpt_scene_sync(s);
+    if (st) return st;
+    unsigned long long h[GPT_STAT_WORDS];
+    HIP_TRY(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    for (int d = 0; d < GPT_MAX_DEPTH; d++) {
+        out->live_at_depth[d] = h[GPT_STAT_LIVE0 + d];
+        out->path_bounces += h[GPT_STAT_LIVE0 + d];
+    }
+    out->passes = s->passes;
+    out->kd_nodes_visited = h[GPT_STAT_KD_NODES];
+    out->kd_tris_tested = h[GPT_STAT_KD_TRIS];
+    out->device_ms_trace = s->ms_trace;
+    out->device_ms_total = s->ms_total;
+    out->trace_launches = s->trace_launches;
+    return GPT_OK;
+}
+
+gpt_status gpt_scene_info(gpt_scene* s, int* n_nodes, int* n_refs, int* tree_depth, int* n_materials) {
+    if (!s) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene");
+    if (n_nodes) *n_nodes = s->n_nodes;
+    if (n_refs) *n_refs = s->n_refs;
+    if (tree_depth) *tree_depth = s->tree_depth;
+    (void)n_materials;
+    return GPT_OK;
+}
+
+gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, int32_t* prim, float* t) {
+    gpt_status st = check_render_args(s, cam);
+    if (st) return st;
+    if (!prim || !t) return fail(GPT_ERR_INVALID_ARGUMENT, "null output");
+    HIP_TRY(hipSetDevice(s->device));
+    const int N = s->numPixels;
+    const CamPre cp = make_cam(cam, s->params.row_stride_is_width);
+    unsigned* counts = s->d_counters;
+    unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
+    gptk_camera(s->stream, pixel_grid(N), &cp, N, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0],
+                s->d_pass, counts);
+    const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
+    // statistics are not touched by this query: use a scratch copy of the stats words
+    unsigned long long* scratch_stats = nullptr;
+    HIP_TRY(hipMalloc((void**)&scratch_stats, sizeof(unsigned long long) * GPT_STAT_WORDS));
+    HIP_TRY(hipMemsetAsync(scratch_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
+    const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
+    gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit, counts, work,
+                   scratch_stats, s->d_spill, s->spill_stride);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> h((size_t)N * 2);
+    HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit, h.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipFree(scratch_stats));
+    for (int i = 0; i < N; i++) {
+        t[i] = h[2 * (size_t)i];
+        memcpy(&prim[i], &h[2 * (size_t)i + 1], 4);
+    }
+    return GPT_OK;
+}
+
+gpt_status gpt_debug_intersect(gpt_scene* s, const float* rays, int n, int use_kdtree, int32_t* tri, float* t) {
+    if (!s || !rays || !tri || !t || n < 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return GPT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    float* d_rays = nullptr; int32_t* d_tri = nullptr; float* d_t = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
+    HIP_TRY(hipMalloc((void**)&d_tri, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
+    const int grid = std::max(1, std::min(kTraceGrid, (n + kBlock - 1) / kBlock));
+    gptk_debug_intersect(s->stream, grid, &s->geom, use_kdtree ? 1 : 0, d_rays, n, d_tri, d_t, s->d_spill,
+                         s->spill_stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipFree(d_rays));
+    HIP_TRY(hipFree(d_tri));
+    HIP_TRY(hipFree(d_t));
+    return GPT_OK;
+}
+
+// ---- kd-tree builder through the C-ABI ----------------------------------------
+struct gpt_kdtree { gptkd::Tree tree; };
+
+gpt_status gpt_kdtree_build(const float* tri_vertices, int n_tris, int small_threshold, gpt_kdtree** out_tree) {
+    if (!out_tree || n_tris < 0 || (n_tris > 0 && !tri_vertices)) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    gpt_kdtree* t = new gpt_kdtree();
+    gptkd::BuildParams bp;
+    if (small_threshold > 0) bp.small_threshold = small_threshold;
+    gptkd::build(tri_vertices, n_tris, bp, t->tree);
+    *out_tree = t;
+    return GPT_OK;
+}
+gpt_status gpt_kdtree_info(const gpt_kdtree* t, int* n_nodes, int* n_refs, int* max_depth, float bounds[6]) {
+    if (!t) return fail(GPT_ERR_INVALID_ARGUMENT, "null tree");
+    if (n_nodes) *n_nodes = (int)t->tree.nodes.size();
+    if (n_refs) *n_refs = (int)t->tree.refs.size();
+    if (max_depth) *max_depth = t->tree.max_depth;
+    if (bounds) memcpy(bounds, t->tree.bounds, 24);
+    return GPT_OK;
+}
+gpt_status gpt_kdtree_copy(const gpt_kdtree* t, uint32_t* nodes, int32_t* refs) {
+    if (!t) return fail(GPT_ERR_INVALID_ARGUMENT, "null tree");
+    if (nodes) memcpy(nodes, t->tree.nodes.data(), t->tree.nodes.size() * 8);
+    if (refs) memcpy(refs, t->tree.refs.data(), t->tree.refs.size() * 4);
+    return GPT_OK;
+}
+void gpt_kdtree_free(gpt_kdtree* t) { delete t; }
+
+// ---- device memory helpers ---------------------------------------------------
+gpt_status gpt_device_alloc(void** out_ptr, size_t bytes) {
+    if (!out_ptr) return fail(GPT_ERR_INVALID_ARGUMENT, "null output");
+    HIP_TRY(hipMalloc(out_ptr, bytes > 0 ? bytes : 16));
+    return GPT_OK;
+}
+gpt_status gpt_device_upload(void* dst_device, const void* src_host, size_t bytes) {
+    if (bytes == 0) return GPT_OK;
+    HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+gpt_status gpt_device_free(void* ptr) {
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return GPT_OK;
+}
+
+// ---- launchKernel ---------------------------------------------------------------
+namespace {
+struct LaunchCache {
+    std::mutex mu;
+    gpt_scene* scene = nullptr;
+    const void* polys = nullptr; const void* spheres = nullptr;
+    int numPolys = -1, numSpheres = -1;
+    unsigned long long checksum = 0;
+    gpt_render_params params;
+    bool params_set = false;
+    unsigned long long* d_sum = nullptr;
+} g_launch;
+
+[[noreturn]] void die(const char* what) {
+    fprintf(stderr, "%s %s\n", what, g_error.c_str());
+    exit(EXIT_FAILURE);
+}
+}  // namespace
+
+void gpt_launch_kernel_params(const gpt_render_params* params) {
+    std::lock_guard<std::mutex> lock(g_launch.mu);
+    if (params) { g_launch.params = *params; g_launch.params_set = true; }
+    else g_launch.params_set = false;
+    if (g_launch.scene) { gpt_scene_destroy(g_launch.scene); g_launch.scene = nullptr; }
+}
+
+void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, int numPixels, Color* pixels,
+                  int counter, Camera renderCamera) {
+    std::lock_guard<std::mutex> lock(g_launch.mu);
+    LaunchCache& L = g_launch;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { g_error = "no HIP device"; die("launchKernel:"); }
+    // content checksum of the two device arrays: the scene is re-indexed only when it changes
+    if (!L.d_sum && hipMalloc((void**)&L.d_sum, 8) != hipSuccess) { g_error = "hipMalloc"; die("launchKernel:"); }
+    unsigned long long sum = 0;
+    if (hipMemset(L.d_sum, 0, 8) != hipSuccess) { g_error = "hipMemset"; die("launchKernel:"); }
+    if (numPolys > 0) gptk_checksum(nullptr, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
+    if (numSpheres > 0) gptk_checksum(nullptr, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);
+    if (hipMemcpy(&sum, L.d_sum, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        g_error = hipGetErrorString(hipGetLastError());
+        die("launchKernel: checksum failed:");
+    }
+    const bool same = L.scene && L.polys == polys && L.spheres == spheres && L.numPolys == numPolys &&
+                      L.numSpheres == numSpheres && L.checksum == sum;
+    if (!same) {
+        if (L.scene) { gpt_scene_destroy(L.scene); L.scene = nullptr; }
+        std::vector<Poly> hp((size_t)std::max(numPolys, 0));
+        std::vector<Sphere> hs((size_t)std::max(numSpheres, 0));
+        if (numPolys > 0 && hipMemcpy(hp.data(), polys, hp.size() * sizeof(Poly), hipMemcpyDeviceToHost) != hipSuccess) {
+            g_error = "copying polys from the device failed"; die("launchKernel:");
+        }
+        if (numSpheres > 0 && hipMemcpy(hs.data(), spheres, hs.size() * sizeof(Sphere), hipMemcpyDeviceToHost) != hipSuccess) {
+            g_error = "copying spheres from the device failed"; die("launchKernel:");
+        }
+        gpt_render_params rp;
+        if (L.params_set) rp = L.params;
+        else { gpt_render_params_default(&rp); rp.row_stride_is_width = 0; }   // the reference's arithmetic
+        if (gpt_scene_create(hs.data(), numSpheres, hp.data(), numPolys, &rp, dev, &L.scene) != GPT_OK)
+            die("launchKernel: scene upload failed:");
+        L.polys = polys; L.spheres = spheres; L.numPolys = numPolys; L.numSpheres = numSpheres; L.checksum = sum;
+    }
+    if (L.scene->numPixels != numPixels && gpt_scene_reset(L.scene, numPixels) != GPT_OK)
+        die("launchKernel: buffer allocation failed:");
+    if (gpt_render_pass(L.scene, &renderCamera, counter, (float*)pixels) != GPT_OK)
+        die("launchKernel:");
+}
+
+}  // extern "C"

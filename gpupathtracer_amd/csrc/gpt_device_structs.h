@@ -1,0 +1,32 @@
+// gpt_device_structs.h -- kernel argument blocks shared by gpt_kernels.hip and
+// gpt_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kd_traverse.h"
+
+// Per-pass device counters: counts[d] = live paths entering depth d;
+// work[d] / work[SLOTS + d] = work-queue heads of the intersect / shade kernels.
+#define GPT_MAX_DEPTH 64
+#define GPT_MAX_DEPTH_SLOTS 72
+#define GPT_COUNTER_WORDS (3 * GPT_MAX_DEPTH_SLOTS)
+
+// Cumulative 64-bit statistics.
+#define GPT_STAT_LIVE0 0                      // [GPT_MAX_DEPTH] live paths per depth
+#define GPT_STAT_KD_NODES (GPT_MAX_DEPTH + 0)
+#define GPT_STAT_KD_TRIS (GPT_MAX_DEPTH + 1)
+#define GPT_STAT_WORDS (GPT_MAX_DEPTH + 8)
+
+struct DevGeometry {
+    const float4* spheres;     // (centre.xyz, radius)
+    const int* sphere_mat;     // material index per sphere
+    int n_spheres;
+    int n_tris;
+    const float4* tri_nm;      // (Poly.n.xyz, material index as int bits) per triangle
+    const float4* mats;        // 4 x float4 per material:
+                               //   (diffuse.rgb, ior) (specular.rgb, transmits) (emitted.rgb, sigma_s) (sigma_a.rgb, 0)
+    pt::KdView kd;             // nodes, refs, triangle records, root box, slack
+    float ground_elevation;
+    int ground_enabled;
+};

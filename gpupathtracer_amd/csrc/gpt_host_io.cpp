@@ -1,0 +1,314 @@
+// gpt_host_io.cpp -- the callers and data formats either side of the hot path
+// (plain host C++): OBJ loading with the reference loader's semantics, the
+// reference's scene/material/camera tables, and headless image output.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/gpt.h"
+
+extern "C" const char* gpt_last_error(void);
+// gpt_api.cpp owns the error string; this file reports through a setter there.
+extern "C" void gpt_set_last_error_(const char* msg);
+
+namespace {
+
+gpt_status io_fail(gpt_status st, const std::string& msg) {
+    gpt_set_last_error_(msg.c_str());
+    return st;
+}
+
+// SET_DEFAULT_MATERIAL_PROPERTIES (material.h:19-26) with SET_TO_AIR_MEDIUM (medium.h:17-24)
+Material default_material() {
+    Material m;
+    memset(&m, 0, sizeof(m));
+    m.medium.refractiveIndex = (float)1.000293;
+    return m;
+}
+
+void set3(Color& c, double x, double y, double z) { c.x = (float)x; c.y = (float)y; c.z = (float)z; }
+
+struct Preset { const char* name; Material m; };
+
+// path_tracer.cpp:124-215
+std::vector<Preset> make_presets() {
+    std::vector<Preset> v;
+    Material m;
+    m = default_material(); set3(m.diffuseColor, 0.87, 0.15, 0.15); set3(m.specularColor, 1, 1, 1);
+    m.medium.refractiveIndex = (float)1.491; v.push_back({"red", m});
+    m = default_material(); set3(m.diffuseColor, 0.15, 0.87, 0.15); set3(m.specularColor, 1, 1, 1);
+    m.medium.refractiveIndex = (float)1.491; v.push_back({"green", m});
+    m = default_material(); set3(m.diffuseColor, 0.93, 0.33, 0.04); set3(m.specularColor, 1, 1, 1);
+    m.medium.refractiveIndex = (float)1.491; v.push_back({"orange", m});
+    // purple: its diffuse colour is overwritten with black at path_tracer.cpp:150
+    m = default_material(); set3(m.diffuseColor, 0, 0, 0); set3(m.specularColor, 1, 1, 1);
+    m.medium.refractiveIndex = (float)1.491; v.push_back({"purple", m});
+    m = default_material(); set3(m.specularColor, 1, 1, 1); m.medium.refractiveIndex = (float)2.42;
+    m.hasTransmission = true; v.push_back({"glass", m});
+    m = default_material(); set3(m.specularColor, 1, 1, 1); m.hasTransmission = true;
+    m.medium.refractiveIndex = (float)1.62;
+    set3(m.medium.absorptionAndScatteringProperties.absorptionCoefficient, 1.0, 0.01, 1.0);
+    v.push_back({"greenGlass", m});
+    m = default_material(); set3(m.specularColor, 1, 1, 1); m.hasTransmission = true;
+    m.medium.refractiveIndex = (float)1.486;
+    set3(m.medium.absorptionAndScatteringProperties.absorptionCoefficient, 0.6, 0.6, 0.6);
+    m.medium.absorptionAndScatteringProperties.reducedScatteringCoefficient = (float)8.0;
+    v.push_back({"marble", m});
+    m = default_material(); set3(m.specularColor, 1, 1, 1); m.hasTransmission = true;
+    m.medium.refractiveIndex = (float)1.333;
+    set3(m.medium.absorptionAndScatteringProperties.absorptionCoefficient, 0.9, 0.3, 0.02);
+    m.medium.absorptionAndScatteringProperties.reducedScatteringCoefficient = (float)2.0;
+    v.push_back({"something", m});
+    m = default_material(); set3(m.specularColor, 1, 1, 1); m.hasTransmission = true;
+    m.medium.refractiveIndex = (float)1.350;
+    set3(m.medium.absorptionAndScatteringProperties.absorptionCoefficient, 0.02, 5.1, 5.7);
+    m.medium.absorptionAndScatteringProperties.reducedScatteringCoefficient = (float)9.0;
+    v.push_back({"ketchup", m});
+    m = default_material(); set3(m.diffuseColor, 0.9, 0.9, 0.9); v.push_back({"white", m});
+    m = default_material(); set3(m.diffuseColor, 0.4, 0.6, 0.8); set3(m.specularColor, 1, 1, 1);
+    m.medium.refractiveIndex = (float)1.2; v.push_back({"lightBlue", m});
+    m = default_material(); set3(m.specularColor, 0.869, 0.621, 0.027);
+    m.medium.refractiveIndex = (float)1000.0; v.push_back({"gold", m});
+    m = default_material(); set3(m.specularColor, 0.89, 0.89, 0.89);
+    m.medium.refractiveIndex = (float)1000.0; v.push_back({"steel", m});
+    m = default_material(); set3(m.emittedColor, 13, 13, 11); v.push_back({"light", m});
+    return v;
+}
+
+const std::vector<Preset>& presets() {
+    static const std::vector<Preset> p = make_presets();
+    return p;
+}
+
+struct SphereRow { double x, y, z, r; const char* mat; };
+// path_tracer.cpp:217-271
+const SphereRow kSpheres[14] = {
+    {-0.9, 0, -0.9, 0.8, "steel"},      {0.9, -0.5, 1.3, 0.3, "greenGlass"}, {-0.5, -0.4, 1.0, 0.4, "lightBlue"},
+    {-1.0, -0.7, 1.2, 0.1, "lightBlue"}, {-0.5, -0.7, 1.7, 0.1, "lightBlue"}, {0.3, -0.7, 1.4, 0.1, "lightBlue"},
+    {-0.1, -0.7, 0.1, 0.1, "lightBlue"}, {0.2, -0.55, 0.7, 0.25, "lightBlue"}, {0.8, 0, -0.4, 0.8, "green"},
+    {0.8, 1.2, -0.4, 0.4, "green"},      {0.8, 1.8, -0.4, 0.2, "green"},      {0.8, 2.1, -0.4, 0.1, "green"},
+    {0.8, 2.25, -0.4, 0.05, "green"},    {0.8, 2.325, -0.4, 0.025, "green"}};
+
+// BasicMath (basic_math.cpp:5-36): float constants, double arithmetic inside.
+const float kPiF = (float)3.1415926535897932384626422832795028841971;
+float radians_to_degrees(float radians) { float degrees = radians * 180.0 / kPiF; return degrees; }
+float degrees_to_radians(float degrees) { float radians = degrees / 180.0 * kPiF; return radians; }
+float bm_min(float a, float b) { if (a < b) return a; else return b; }
+float bm_max(float a, float b) { if (a > b) return a; else return b; }
+float bm_clamp(float n, float low, float high) { n = bm_min(n, high); n = bm_max(n, low); return n; }
+
+std::vector<std::string> split_spaces(const std::string& s, size_t from) {
+    // std::getline(stream, tok, ' ') semantics: empty tokens between adjacent
+    // spaces are kept, a trailing delimiter yields no extra token.
+    std::vector<std::string> out;
+    std::istringstream ss(s.substr(from));
+    std::string tok;
+    while (std::getline(ss, tok, ' ')) out.push_back(tok);
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gpt_free(void* p) { free(p); }
+
+int gpt_default_scene_sphere_count(void) { return 14; }
+
+gpt_status gpt_material_preset(const char* name, Material* out) {
+    if (!name || !out) return io_fail(GPT_ERR_INVALID_ARGUMENT, "null argument");
+    for (const Preset& p : presets())
+        if (strcmp(p.name, name) == 0) { *out = p.m; return GPT_OK; }
+    return io_fail(GPT_ERR_INVALID_ARGUMENT, std::string("unknown material preset: ") + name);
+}
+
+void gpt_default_scene(Sphere* out) {
+    for (int i = 0; i < 14; i++) {
+        memset(&out[i], 0, sizeof(Sphere));
+        out[i].position.x = (float)kSpheres[i].x;
+        out[i].position.y = (float)kSpheres[i].y;
+        out[i].position.z = (float)kSpheres[i].z;
+        out[i].radius = (float)kSpheres[i].r;
+        gpt_material_preset(kSpheres[i].mat, &out[i].material);
+    }
+}
+
+// InteractiveCamera::setResolution/setFOVX/buildRenderCamera
+// (interactive_camera.cpp:61-87)
+void gpt_orbit_camera(float width, float height, float fovx_degrees, float yaw, float pitch, float radius,
+                      float apertureRadius, const float center[3], Camera* out) {
+    memset(out, 0, sizeof(*out));
+    float fovx = fovx_degrees;
+    float fovy = radians_to_degrees(atan(tan(degrees_to_radians(fovx) * 0.5) * (height / width)) * 2.0);
+    float xDirection = sinf(yaw) * cosf(pitch);
+    float yDirection = sinf(pitch);
+    float zDirection = cosf(yaw) * cosf(pitch);
+    out->position.x = center[0] + xDirection * radius;
+    out->position.y = center[1] + yDirection * radius;
+    out->position.z = center[2] + zDirection * radius;
+    out->view.x = -xDirection; out->view.y = -yDirection; out->view.z = -zDirection;
+    out->up.x = 0; out->up.y = 1; out->up.z = 0;
+    out->resolution.x = width; out->resolution.y = height;
+    out->fov.x = fovx; out->fov.y = fovy;
+    out->apertureRadius = apertureRadius;
+    out->focalDistance = radius;
+}
+
+// InteractiveCamera() defaults (interactive_camera.cpp:15-25) + display.cpp:78-85
+void gpt_default_camera(float width, float height, Camera* out) {
+    const float center[3] = {0, 0, 0};
+    gpt_orbit_camera(width, height, 45, 0, (float)0.3, 4, (float)0.04, center, out);
+}
+
+// floatTo8Bit(c / passCounter): color.cpp:41-62, display.cpp:198
+void gpt_tonemap_8bit(const float* sum_rgb, int numPixels, int passes, unsigned char* out_rgb8) {
+    float gamma = 2.2;
+    float oneOverGamma = 1.0 / gamma;
+    for (size_t i = 0; i < (size_t)numPixels * 3; i++) {
+        float c = sum_rgb[i] / (float)passes;
+        float g = std::pow(c, oneOverGamma);
+        out_rgb8[i] = (unsigned char)bm_clamp(g * 255, 0, 255);
+    }
+}
+
+gpt_status gpt_write_ppm(const char* path, const float* sum_rgb, int width, int height, int passes) {
+    if (!path || !sum_rgb || width <= 0 || height <= 0 || passes <= 0)
+        return io_fail(GPT_ERR_INVALID_ARGUMENT, "bad argument to gpt_write_ppm");
+    std::vector<unsigned char> px((size_t)width * height * 3);
+    gpt_tonemap_8bit(sum_rgb, width * height, passes, px.data());
+    FILE* f = fopen(path, "wb");
+    if (!f) return io_fail(GPT_ERR_IO, std::string("cannot open ") + path);
+    fprintf(f, "P6\n%d %d\n255\n", width, height);
+    size_t w = fwrite(px.data(), 1, px.size(), f);
+    fclose(f);
+    if (w != px.size()) return io_fail(GPT_ERR_IO, std::string("short write to ") + path);
+    return GPT_OK;
+}
+
+gpt_status gpt_write_pfm(const char* path, const float* sum_rgb, int width, int height, int passes) {
+    if (!path || !sum_rgb || width <= 0 || height <= 0 || passes <= 0)
+        return io_fail(GPT_ERR_INVALID_ARGUMENT, "bad argument to gpt_write_pfm");
+    FILE* f = fopen(path, "wb");
+    if (!f) return io_fail(GPT_ERR_IO, std::string("cannot open ") + path);
+    fprintf(f, "PF\n%d %d\n-1.0\n", width, height);       // negative scale: little endian
+    std::vector<float> row((size_t)width * 3);
+    for (int y = height - 1; y >= 0; y--) {               // PFM rows run bottom to top
+        for (int i = 0; i < width * 3; i++) row[(size_t)i] = sum_rgb[(size_t)y * width * 3 + i] / (float)passes;
+        if (fwrite(row.data(), 4, row.size(), f) != row.size()) { fclose(f); return io_fail(GPT_ERR_IO, "short write"); }
+    }
+    fclose(f);
+    return GPT_OK;
+}
+
+// objLoader::objLoader (objcore/objloader.cpp:18-122) + PathTracer::prepMesh
+// (path_tracer.cpp:52-69) + the poly loop of createDeviceData (:275-278).
+gpt_status gpt_obj_load(const char* path, const Material* material, Poly** out_polys, int* out_numPolys,
+                        float bbox[6]) {
+    if (!path || !out_polys || !out_numPolys) return io_fail(GPT_ERR_INVALID_ARGUMENT, "null argument");
+    *out_polys = nullptr;
+    *out_numPolys = 0;
+    std::ifstream in(path);
+    if (!in.is_open()) return io_fail(GPT_ERR_IO, std::string("ERROR: ") + path + " could not be found");
+
+    std::vector<float> points, normals;
+    std::vector<std::vector<int>> faces, facenormals;
+    while (in.good()) {
+        std::string line;
+        std::getline(in, line);
+        if (line.empty()) line = "42";
+        const char c0 = line[0], c1 = line.size() > 1 ? line[1] : '\0';
+        if (c0 == 'v' && c1 == 't') {
+            continue;   // texture coordinates never reach the renderer
+        } else if (c0 == 'v') {
+            std::vector<std::string> t = split_spaces(line, 0);
+            float xyz[3] = {0, 0, 0};
+            for (int k = 0; k < 3; k++)
+                if ((size_t)(k + 1) < t.size()) xyz[k] = (float)::atof(t[(size_t)k + 1].c_str());
+            std::vector<float>& dst = (c1 == 'n') ? normals : points;
+            dst.insert(dst.end(), xyz, xyz + 3);
+        } else if (c0 == 'f') {
+            std::vector<std::string> t = split_spaces(line, 0);
+            std::vector<int> pl, nl;
+            if (line.find("//") != std::string::npos) {
+                for (size_t k = 1; k < t.size(); k++) {
+                    std::istringstream fs(t[k]);
+                    std::string f;
+                    std::getline(fs, f, '/');
+                    pl.push_back((int)(::atof(f.c_str()) - 1));
+                    std::getline(fs, f, '/');
+                    std::getline(fs, f, ' ');
+                    nl.push_back((int)(::atof(f.c_str()) - 1));
+                }
+                faces.push_back(pl);
+                facenormals.push_back(nl);
+            } else if (line.find("/") != std::string::npos) {
+                for (size_t k = 1; k < t.size(); k++) {
+                    std::istringstream fs(t[k]);
+                    std::string f;
+                    int i = 0;
+                    while (std::getline(fs, f, '/')) {
+                        if (i == 0) pl.push_back((int)(::atof(f.c_str()) - 1));
+                        else if (i == 2) nl.push_back((int)(::atof(f.c_str()) - 1));
+                        i++;
+                    }
+                }
+                faces.push_back(pl);
+                facenormals.push_back(nl);
+            } else {
+                for (size_t k = 1; k < t.size(); k++) pl.push_back((int)(::atof(t[k].c_str()) - 1));
+                faces.push_back(pl);
+            }
+        }
+    }
+    const int npts = (int)(points.size() / 3), nnrm = (int)(normals.size() / 3);
+    Material mat = material ? *material : default_material();
+    Poly* polys = (Poly*)calloc(faces.size() > 0 ? faces.size() : 1, sizeof(Poly));
+    if (!polys) return io_fail(GPT_ERR_OUT_OF_MEMORY, "out of memory");
+    for (size_t i = 0; i < faces.size(); i++) {
+        const std::vector<int>& fc = faces[i];
+        if (fc.size() < 3) { free(polys); return io_fail(GPT_ERR_PARSE, "face with fewer than 3 vertices"); }
+        for (int k = 0; k < 3; k++)
+            if (fc[(size_t)k] < 0 || fc[(size_t)k] >= npts) { free(polys); return io_fail(GPT_ERR_PARSE, "face vertex index out of range"); }
+        Poly& p = polys[i];
+        p.position.x = (float)0.0; p.position.y = (float)-0.8; p.position.z = (float)0.0;
+        const float* a = &points[3 * (size_t)fc[0]];
+        const float* b = &points[3 * (size_t)fc[1]];
+        const float* c = &points[3 * (size_t)fc[2]];
+        p.p0.x = a[0]; p.p0.y = a[1]; p.p0.z = a[2];
+        p.p1.x = b[0]; p.p1.y = b[1]; p.p1.z = b[2];
+        p.p2.x = c[0]; p.p2.y = c[1]; p.p2.z = c[2];
+        if (i < facenormals.size() && !facenormals[i].empty()) {
+            int ni = facenormals[i][0];
+            if (ni < 0 || ni >= nnrm) { free(polys); return io_fail(GPT_ERR_PARSE, "face normal index out of range"); }
+            p.n.x = normals[3 * (size_t)ni]; p.n.y = normals[3 * (size_t)ni + 1]; p.n.z = normals[3 * (size_t)ni + 2];
+        } else {
+            // no normals in the file: geometric normal, normalize(cross(p1-p0, p2-p0)) (obj.cpp:87-89)
+            float ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+            float vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+            float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+            float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            if (len > 0) { nx /= len; ny /= len; nz /= len; }
+            p.n.x = nx; p.n.y = ny; p.n.z = nz;
+        }
+        p.material = mat;
+    }
+    if (bbox) {
+        for (int k = 0; k < 6; k++) bbox[k] = 0;
+        for (int i = 0; i < npts; i++)
+            for (int k = 0; k < 3; k++) {
+                float v = points[3 * (size_t)i + k];
+                if (i == 0 || v < bbox[k]) bbox[k] = v;
+                if (i == 0 || v > bbox[3 + k]) bbox[3 + k] = v;
+            }
+    }
+    *out_polys = polys;
+    *out_numPolys = (int)faces.size();
+    return GPT_OK;
+}
+
+}  // extern "C"

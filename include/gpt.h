@@ -224,6 +224,14 @@ typedef struct gpt_stats {
 } gpt_stats;
 gpt_status gpt_get_stats(gpt_scene* scene, gpt_stats* out);
 
+/* Profiling switches (both off by default).  time_kernels: bracket every
+ * intersect kernel and every pass with HIP events on the scene's stream and
+ * report the sums in gpt_stats.device_ms_*.  count_kd_work: run the
+ * instrumented intersect kernel that counts kd nodes visited / triangles tested. */
+gpt_status gpt_scene_set_profiling(gpt_scene* scene, int time_kernels, int count_kd_work);
+/* Size of the scene's kd-tree. */
+gpt_status gpt_scene_info(gpt_scene* scene, int* n_nodes, int* n_refs, int* tree_depth, int* reserved);
+
 /* First-hit record of every primary ray of pass `counter` (debug/parity):
  * prim[i] = -1 miss, -2 ground, 0x40000000|s sphere s, otherwise triangle
  * index; t[i] = hit distance. Host arrays of numPixels entries. */

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU
+oracle (oracle/pathtracer_oracle.c) on the same inputs.
+
+Tolerances.  Integer/index work (RNG, hit primitive ids, live-path counts with
+a pinhole camera, kd-tree vs brute force) is compared exactly.  Radiance is
+floating point: a pass agrees when every sample is within 1e-4 relative
+(denominator floored at 1e-3) except for a bounded fraction of samples whose
+path took a different branch because a sin/cos/log/exp differed in its last
+bit from the host libm (the device rounds the double result once; glibc's
+float functions are within 0.56 ulp).  Those are bounded at 0.2 % of samples,
+and the pass mean must agree to 2e-4 relative.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes as S
+from gpupathtracer_amd import api, meshes
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+FLIP_FRACTION = 2e-3
+
+
+def rel_err(got, ref):
+    return (np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)).max(axis=1)
+
+
+def check_pass(got, ref, flip_fraction=FLIP_FRACTION):
+    r = rel_err(got, ref)
+    bad = float((r > REL_TOL).mean())
+    assert bad <= flip_fraction, "fraction of samples beyond 1e-4: %g" % bad
+    gm, rm = got.mean(axis=0, dtype=np.float64), ref.mean(axis=0, dtype=np.float64)
+    assert np.all(np.abs(gm - rm) <= 2e-4 * np.maximum(rm, 1e-3) + 1e-12 + 3 * bad), (gm, rm)
+    return bad
+
+
+def test_primary_hits_pinhole_exact():
+    """No lens sampling -> no transcendental on the primary path: ids and t bit-exact."""
+    w = h = 256
+    cam = S.orbit_camera(w, h, aperture=0.0)
+    sph = S.default_spheres()
+    with api.Scene(sph, None, api.render_params(max_depth=4, row_stride_is_width=0)) as sc:
+        prim, t = sc.primary_hits(cam, 5)
+    ref = O.render_pass(sph, None, cam, 5, O.params(max_depth=1), want_hits=True)
+    assert np.array_equal(prim, ref["hits"]["prim"])
+    assert np.array_equal(t.view(np.int32), ref["hits"]["t"].view(np.int32))
+
+
+def test_primary_hits_with_lens():
+    w = h = 256
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    with api.Scene(sph, None, api.render_params(max_depth=4, row_stride_is_width=0)) as sc:
+        prim, t = sc.primary_hits(cam, 0)
+    ref = O.render_pass(sph, None, cam, 0, O.params(max_depth=1), want_hits=True)
+    assert (prim != ref["hits"]["prim"]).mean() < 1e-4
+    same = prim == ref["hits"]["prim"]
+    assert np.allclose(t[same], ref["hits"]["t"][same], rtol=1e-4, atol=0)
+    assert (t[same] != ref["hits"]["t"][same]).mean() < 0.02
+
+
+@pytest.mark.parametrize("depth", [8, 30])
+def test_default_scene_pass(depth):
+    """The reference's default scene (14 spheres, ground, sky), per-sample radiance."""
+    w = h = 256
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    with api.Scene(sph, None, api.render_params(max_depth=depth, row_stride_is_width=0)) as sc:
+        for counter in (0, 1, 7):
+            got = sc.render_pass(cam, counter)
+            ref = O.render_pass(sph, None, cam, counter, O.params(max_depth=depth))
+            check_pass(got, ref["rgb"])
+        st = sc.stats()
+    assert st["passes"] == 3
+    assert st["live_at_depth"][0] == 3 * w * h
+
+
+def test_live_counts_match_oracle_pinhole():
+    w = h = 128
+    cam = S.orbit_camera(w, h, aperture=0.0)
+    sph = S.default_spheres()
+    depth = 12
+    with api.Scene(sph, None, api.render_params(max_depth=depth, row_stride_is_width=0)) as sc:
+        sc.render_pass(cam, 3, want_pixels=False)
+        st = sc.stats()
+    ref = O.render_pass(sph, None, cam, 3, O.params(max_depth=depth))
+    live = st["live_at_depth"][:depth]
+    # identical up to the rare last-bit branch flips
+    assert np.all(np.abs(live - ref["live"]) <= np.maximum(2, ref["live"] // 500)), (live, ref["live"])
+
+
+def test_all_material_branches():
+    """Every sphere gets a different preset so that reflection, refraction, absorption-only
+    media, scattering media and pure diffuse are all exercised."""
+    names = ["steel", "greenGlass", "marble", "ketchup", "something", "glass", "gold", "white",
+             "red", "orange", "purple", "lightBlue", "light", "green"]
+    sph = S.spheres_with(names)
+    w = h = 192
+    cam = S.orbit_camera(w, h)
+    depth = 16
+    with api.Scene(sph, None, api.render_params(max_depth=depth, row_stride_is_width=0)) as sc:
+        got = sc.render_pass(cam, 2)
+    ref = O.render_pass(sph, None, cam, 2, O.params(max_depth=depth))
+    check_pass(got, ref["rgb"], flip_fraction=4e-3)
+
+
+@pytest.mark.parametrize("use_kd", [0, 1])
+def test_mesh_scene_pass(use_kd):
+    """Glass diamond + subsurface coil + spheres: brute force (the reference's loop) and kd-tree."""
+    w = h = 128
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    dv, dn = meshes.load_asset("diamond")
+    dv = meshes.transform(dv, 0.8, (0.2, -2.2, 2.6))
+    cv, cn = meshes.load_asset("coil")
+    cv = meshes.transform(cv, 0.25, (-1.2, -2.2, 1.2))
+    polys = np.concatenate([meshes.polys_from_triangles(dv, dn, S.MATERIALS["glass"]),
+                            meshes.polys_from_triangles(cv, cn, S.MATERIALS["marble"])])
+    depth = 8
+    with api.Scene(sph, polys, api.render_params(max_depth=depth, row_stride_is_width=0, use_kdtree=use_kd)) as sc:
+        prim, t = sc.primary_hits(cam, 1)
+        got = sc.render_pass(cam, 1)
+    ref = O.render_pass(sph, polys, cam, 1, O.params(max_depth=depth), want_hits=True)
+    assert (prim != ref["hits"]["prim"]).mean() < 2e-4
+    assert ((prim >= 0) & (prim < polys.size)).sum() > 100      # the meshes are in view
+    check_pass(got, ref["rgb"], flip_fraction=4e-3)
+
+
+def test_kdtree_equals_brute_force_on_device():
+    """Closest-triangle queries: traversal must return the brute-force loop's answer, bit for bit."""
+    v, n = meshes.load_asset("cow")
+    v, n = meshes.subdivide(v, n, 1)                     # 23 216 triangles
+    polys = meshes.polys_from_triangles(v, n, S.MATERIALS["glass"])
+    rng = np.random.default_rng(7)
+    m = 300000
+    lo, hi = v.reshape(-1, 3).min(axis=0), v.reshape(-1, 3).max(axis=0)
+    ctr, ext = (lo + hi) / 2, (hi - lo).max()
+    o = ((rng.random((m, 3), dtype=np.float32) * 3 - 1.5) * ext + ctr).astype(np.float32)
+    tgt = ((rng.random((m, 3), dtype=np.float32) - 0.5) * ext + ctr).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    # degenerate families: axis-parallel directions, origins on mesh vertices
+    k = 20000
+    rays[:k, 3:] = 0
+    rays[np.arange(k), 3 + rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    rays[k:2 * k, :3] = v.reshape(-1, 3)[rng.integers(0, v.size // 3, k)]
+    with api.Scene(None, polys, api.render_params(max_depth=1)) as sc:
+        tk, ttk = sc.intersect(rays, use_kdtree=True)
+        tb, ttb = sc.intersect(rays, use_kdtree=False)
+    assert (tb >= 0).sum() > 50000
+    assert np.array_equal(tk, tb)
+    assert np.array_equal(ttk.view(np.int32), ttb.view(np.int32))
+    # and the device brute force is the oracle's loop
+    sub = slice(0, 4000)
+    to, tto = O.closest_triangle(v, rays[sub])
+    assert np.array_equal(to, tb[sub]) and np.array_equal(tto.view(np.int32), ttb[sub].view(np.int32))
+
+
+def test_image_accumulates_passes_in_order():
+    """image += pass, float32, in counter order (path_tracer.cpp:100-103)."""
+    w = h = 96
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    with api.Scene(sph, None, api.render_params(max_depth=6)) as sc:
+        acc = np.zeros((w * h, 3), dtype=np.float32)
+        for c in range(5):
+            acc += sc.render_pass(cam, c)
+        img, passes = sc.accum_download()
+        assert passes == 5 and np.array_equal(img, acc)
+        sc.reset(w * h)
+        sc.render_range(cam, 0, 5)
+        img2, passes2 = sc.accum_download()
+        assert passes2 == 5 and np.array_equal(img2, acc)
+
+
+def test_launch_kernel_drop_in():
+    """The reference entry point with device-resident Sphere/Poly arrays."""
+    w = h = 64
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    bv, bn = meshes.load_asset("box")
+    bv = meshes.transform(bv, 0.3, (0.0, -0.5, 1.8))
+    polys = meshes.polys_from_triangles(bv, bn, S.MATERIALS["glass"])
+    d_s = api.device_alloc(sph.nbytes)
+    d_p = api.device_alloc(polys.nbytes)
+    api.device_upload(d_s, sph)
+    api.device_upload(d_p, polys)
+    try:
+        api.launch_kernel_params(api.render_params(max_depth=8, row_stride_is_width=0))
+        px0 = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 0, cam)
+        px1 = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 1, cam)
+        with api.Scene(sph, polys, api.render_params(max_depth=8, row_stride_is_width=0)) as sc:
+            want0 = sc.render_pass(cam, 0)
+            want1 = sc.render_pass(cam, 1)
+        assert np.array_equal(px0, want0) and np.array_equal(px1, want1)
+        ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=8))
+        check_pass(px0, ref["rgb"], flip_fraction=4e-3)
+        # a changed scene behind the same pointers is picked up
+        sph2 = sph.copy()
+        sph2[0]["radius"] = 0.5
+        api.device_upload(d_s, sph2)
+        px2 = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 0, cam)
+        assert not np.array_equal(px2, px0)
+    finally:
+        api.launch_kernel_params(None)
+        api.device_free(d_s)
+        api.device_free(d_p)
+
+
+def test_non_square_stride_modes():
+    """Width-stride fix vs the reference's arithmetic: identical on squares, both match the oracle."""
+    sph = S.default_spheres()
+    cam = S.orbit_camera(160, 90)
+    for mode in (0, 1):
+        with api.Scene(sph, None, api.render_params(max_depth=6, row_stride_is_width=mode)) as sc:
+            got = sc.render_pass(cam, 0)
+        ref = O.render_pass(sph, None, cam, 0, O.params(max_depth=6, row_stride_is_width=mode))
+        check_pass(got, ref["rgb"], flip_fraction=4e-3)
+
+
+def test_invalid_arguments_are_reported():
+    sph = S.default_spheres()
+    with pytest.raises(api.GptError):
+        api.Scene(sph, None, api.render_params(max_depth=1000))
+    with api.Scene(sph, None, api.render_params(max_depth=2)) as sc:
+        sc.reset(64 * 64)
+        cam = S.orbit_camera(32, 32)
+        with pytest.raises(api.GptError):
+            # resolution does not match the buffers
+            from gpupathtracer_amd import _lib
+            import ctypes
+            c = np.array(cam, dtype=api.CAMERA_DTYPE).reshape(1)
+            api._check(_lib.lib().gpt_render_pass(sc._h, c.ctypes.data_as(ctypes.c_void_p), 0, None))
