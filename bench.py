@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is ONE sample-per-pixel pass (launchKernel's unit of work) over the
+whole frame of the workload.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank renders its own K passes -- a disjoint range
+of pass counters, i.e. independently seeded samples -- and the float4
+accumulation images are sum-reduced once with RCCL at the end of the timed
+region; per-GPU work is fixed, so scaling is weak.
+
+Workload (BASELINE.json `metric`): the reference scene as launchKernel would
+see it with its mesh path enabled on a heavy cow: the 14 default spheres,
+ground and sky (path_tracer.cpp:116-271), plus `cow_heavy` = cow.obj after 4
+rounds of 1->4 midpoint subdivision (1 485 824 triangles, all glass as
+path_tracer.cpp:275-278 assigns), default orbit camera, 1920x1080, depth 8,
+kd-tree traversal.  Inputs (scene, tree, buffers) are resident in HBM before
+the timed region starts.
+
+Rank 0 prints one JSON line; `roofline` describes the dominant kernel
+(k_intersect, the kd-tree traversal) and `cpu_baseline` the CPU oracle timed on
+a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
+
+
+def build_workload(name, subdiv):
+    from gpupathtracer_amd import api, meshes
+    spheres = api.default_scene()
+    if name == "cow_heavy":
+        v, n = meshes.load_asset("cow")
+        v, n = meshes.subdivide(v, n, subdiv)
+        polys = meshes.polys_from_triangles(v, n, api.material_preset("glass"))
+    elif name == "spheres":
+        polys = None
+    else:
+        raise SystemExit("unknown workload " + name)
+    return spheres, polys
+
+
+class CudaArray:
+    """Minimal __cuda_array_interface__ holder so torch can wrap the scene's image in place."""
+
+    def __init__(self, ptr, n_floats):
+        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False),
+                                         "version": 2}
+
+
+def cpu_baseline(spheres, polys, cam, depth, target_seconds=12.0):
+    """The oracle (reference algorithm, brute-force triangle loop) on a strided pixel subset."""
+    import oracle_lib as O
+    w, h = int(cam["resolution"][0]), int(cam["resolution"][1])
+    p = O.params(max_depth=depth, row_stride_is_width=1)
+    threads = O.num_threads()
+    # calibrate on a tiny subset, then size the sample for ~target_seconds
+    def subset(stride):
+        ys, xs = np.meshgrid(np.arange(stride // 2, h, stride), np.arange(stride // 2, w, stride), indexing="ij")
+        return (ys * w + xs).astype(np.int32).ravel()
+    ids = subset(120)
+    t0 = time.perf_counter()
+    r = O.render_pass(spheres, polys, cam, 0, p, pixel_ids=ids)
+    dt = time.perf_counter() - t0
+    per_px = dt / max(1, ids.size)
+    want_px = max(ids.size, int(target_seconds / max(per_px, 1e-9)))
+    stride = max(4, int(np.sqrt(w * h / want_px)))
+    ids = subset(stride)
+    t0 = time.perf_counter()
+    r = O.render_pass(spheres, polys, cam, 0, p, pixel_ids=ids)
+    dt = time.perf_counter() - t0
+    return {
+        "value": r["bounces"] / dt / 1e6,
+        "unit": "Mpath-bounces/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "pass counter 0, every %dth pixel in x and y of the %dx%d frame (%d paths, %d path-bounces, "
+                  "%.1f s), reference algorithm with its brute-force triangle loop"
+                  % (stride, w, h, ids.size, r["bounces"], dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cow_heavy")
+    ap.add_argument("--subdiv", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=8, help="passes traced together per launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gpupathtracer_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    spheres, polys = build_workload(args.workload, args.subdiv)
+    cam = api.default_camera(args.width, args.height)
+    n_pix = args.width * args.height
+    K, W = args.steps, args.warmup
+
+    params = api.render_params(max_depth=args.depth, row_stride_is_width=1, use_kdtree=1,
+                               passes_in_flight=args.batch)
+    t_build = time.perf_counter()
+    scene = api.Scene(spheres, polys, params, device=local_rank)
+    t_build = time.perf_counter() - t_build
+    scene.reset(n_pix)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        scene.sync()
+        torch.cuda.synchronize()
+
+    # rank r owns pass counters [r*(K+W), (r+1)*(K+W)): disjoint, independently seeded samples
+    base = rank * (K + W)
+
+    # ---- untimed: kd work per path-bounce (instrumented kernel), then warm-up ----
+    scene.set_profiling(time_kernels=False, count_kd_work=True)
+    scene.render_range(cam, base, base + 1)
+    st = scene.stats()
+    pb1 = max(1, st["path_bounces"])
+    nodes_per_pb = st["kd_nodes_visited"] / pb1
+    tris_per_pb = st["kd_tris_tested"] / pb1
+    hit_frac = st["hits"] / pb1
+    scene.set_profiling(time_kernels=False, count_kd_work=False)
+    scene.render_range(cam, base, base + W)
+    scene.reset(n_pix)
+    scene.set_profiling(time_kernels=True, count_kd_work=False)
+
+    img_ptr, img_bytes = scene.accum_device_ptr()
+    image = torch.as_tensor(CudaArray(img_ptr, img_bytes // 4), device=torch.device("cuda", local_rank))
+
+    # ---- timed region: exactly K passes per rank + the sum-reduce of the images ----
+    barrier()
+    t0 = time.perf_counter()
+    scene.render_range(cam, base + W, base + W + K, sync=True)
+    if distributed:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = scene.stats()
+    t = torch.tensor([elapsed, float(st["path_bounces"])], dtype=torch.float64, device="cuda")
+    if distributed:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, total_pb = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, total_pb = elapsed, float(st["path_bounces"])
+
+    if rank == 0:
+        n_spheres = int(spheres.size)
+        bytes_per_pb = 124.0 + 8.0 * nodes_per_pb + 40.0 * tris_per_pb + 16.0 * n_spheres + 72.0 * hit_frac
+        launches = max(1, st["trace_launches"])
+        avg_launch_s = st["device_ms_trace"] / 1e3 / launches
+        pb_per_launch = st["path_bounces"] / launches
+        achieved = bytes_per_pb * pb_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.traffic_file):
+            try:
+                tj = json.load(open(args.traffic_file))
+                traffic = tj.get("k_intersect_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpath-bounces/s",
+            "value": total_pb / elapsed_max / 1e6,
+            "unit": "Mpath-bounces/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed_max / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "spp_per_s": world * K / elapsed_max,
+            "config": {
+                "workload": "%s: cow.obj subdivided %dx (%d triangles, glass) + the reference's 14 spheres, "
+                            "ground and sky; default orbit camera %dx%d, depth %d, 1 spp per step, kd-tree"
+                            % (args.workload, args.subdiv, 0 if polys is None else polys.size,
+                               args.width, args.height, args.depth),
+                "passes_per_gpu": K,
+                "passes_per_launch": args.batch,
+                "parallelism": "spp-sharded x%d, one RCCL sum-reduce of the float4 image" % world,
+                "bounces_per_path": st["path_bounces"] / max(1, K * n_pix),
+                "kd": dict(scene.info(), build_and_upload_s=round(t_build, 2)),
+            },
+            "roofline": {
+                "kernel": "k_intersect<kd>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_path_bounce": bytes_per_pb,
+                "kd_nodes_per_path_bounce": nodes_per_pb,
+                "tris_per_path_bounce": tris_per_pb,
+                "hit_fraction": hit_frac,
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "launches": launches,
+                "path_bounces_per_launch": pb_per_launch,
+                "intersect_share_of_pass": st["device_ms_trace"] / max(1e-9, st["device_ms_total"]),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(spheres, polys if polys is not None else None, cam, args.depth)
+        print(json.dumps(out))
+    scene.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpt_hip.so")
+LIB_PATH = os.environ.get("GPT_LIB_PATH", os.path.join(_HERE, "lib", "libgpt_hip.so"))
 
 _lib = None
 
@@ -18,6 +18,7 @@ class GptStats(ctypes.Structure):
         ("passes", ctypes.c_uint64),
         ("kd_nodes_visited", ctypes.c_uint64),
         ("kd_tris_tested", ctypes.c_uint64),
+        ("hits", ctypes.c_uint64),
         ("device_ms_trace", ctypes.c_double),
         ("device_ms_total", ctypes.c_double),
         ("trace_launches", ctypes.c_uint64),

@@ -130,6 +130,7 @@ class Scene:
             "passes": int(st.passes),
             "kd_nodes_visited": int(st.kd_nodes_visited),
             "kd_tris_tested": int(st.kd_tris_tested),
+            "hits": int(st.hits),
             "device_ms_trace": float(st.device_ms_trace),
             "device_ms_total": float(st.device_ms_total),
             "trace_launches": int(st.trace_launches),

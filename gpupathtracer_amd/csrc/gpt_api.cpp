@@ -25,15 +25,16 @@ using pt::TriRec;
 
 // kernels (gpt_kernels.hip)
 extern "C" {
-void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, uint32_t seed, float4* ray_o,
-                 float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts);
+void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, int numPasses, uint32_t seed0,
+                 float4* ray_o, float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts);
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
-                    unsigned long long* stats, uint32_t* spill, size_t spill_stride);
-void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed,
-                const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below);
+void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
+                int numPixels, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work);
-void gptk_finish(hipStream_t s, int grid, int numPixels, const float4* pass_rgb, float4* image, float* pass_out3);
+void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
+                 float* pass_out3);
 void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
                           int32_t* tri, float* t_out, uint32_t* spill, size_t spill_stride);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
@@ -128,6 +129,8 @@ struct gpt_scene {
 
     // per-pixel / per-path buffers
     int numPixels = 0;
+    int batch = 1;                           // passes traced together per launch
+    unsigned refill_below = 32;              // k_intersect_kd: refill a wave when fewer lanes are busy
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};
@@ -209,10 +212,12 @@ int pixel_grid(int numPixels) {
     return std::max(1, std::min(g, 4096));
 }
 
-// Enqueue one pass.  pass3: optional device buffer receiving this pass as packed float3.
-gpt_status enqueue_pass(gpt_scene* s, const Camera* cam, int counter, float* pass3) {
+// Enqueue `P` consecutive passes (counters counter0 .. counter0+P-1) traced together:
+// every kernel launch covers the live paths of all P passes.  pass3: optional device
+// buffer receiving the (last) pass as packed float3.
+gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, float* pass3) {
     const int N = s->numPixels;
-    const uint32_t seed = (uint32_t)counter;
+    const uint32_t seed0 = (uint32_t)counter0;
     const CamPre cp = make_cam(cam, s->params.row_stride_is_width);
     ShadeParams sp;
     sp.ray_bias = s->params.ray_bias;
@@ -220,35 +225,37 @@ gpt_status enqueue_pass(gpt_scene* s, const Camera* cam, int counter, float* pas
     unsigned* counts = s->d_counters;
     unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
     const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
+    const long long total = (long long)N * P;
 
     size_t e0 = 0, e1 = 0;
     if (s->profile) { gpt_status st = get_event(s, &e0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[e0], s->stream)); }
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
-    gptk_camera(s->stream, pixel_grid(N), &cp, N, seed, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_pass, counts);
-    const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
+    gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &cp, N, P, seed0, s->d_ray_o[0],
+                s->d_ray_d[0], s->d_thr[0], s->d_pass, counts);
+    const int grid = (int)std::max<long long>(1, std::min<long long>(kTraceGrid, (total + kBlock - 1) / kBlock));
     for (int depth = 0; depth < s->params.max_depth; depth++) {
         const int in = depth & 1, out = in ^ 1;
         size_t t0 = 0, t1 = 0;
         if (s->profile) { gpt_status st = get_event(s, &t0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[t0], s->stream)); }
         gptk_intersect(s->stream, grid, &s->geom, use_kd, s->kd_stats ? 1 : 0, depth, s->d_ray_o[in], s->d_ray_d[in],
-                       s->d_hit, counts, work, s->d_stats, s->d_spill, s->spill_stride);
+                       s->d_hit, counts, work, s->d_stats, s->d_spill, s->spill_stride, s->refill_below);
         if (s->profile) {
             gpt_status st = get_event(s, &t1); if (st) return st;
             HIP_TRY(hipEventRecord(s->ev_pool[t1], s->stream));
             s->trace_pairs.push_back({t0, t1});
         }
-        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in], s->d_hit,
-                   s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
+        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, N, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
+                   s->d_hit, s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
     }
-    gptk_finish(s->stream, pixel_grid(N), N, s->d_pass, s->d_image, pass3);
+    gptk_finish(s->stream, pixel_grid(N), N, P, s->d_pass, s->d_image, pass3);
     HIP_TRY(hipGetLastError());
     if (s->profile) {
         gpt_status st = get_event(s, &e1); if (st) return st;
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->stream));
         s->total_pairs.push_back({e0, e1});
     }
-    s->passes++;
+    s->passes += (uint64_t)P;
     return GPT_OK;
 }
 
@@ -278,6 +285,7 @@ void gpt_render_params_default(gpt_render_params* p) {
     p->row_stride_is_width = 1;
     p->use_kdtree = 1;
     p->kd_small_threshold = 64;
+    p->passes_in_flight = 8;
 }
 
 gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* polys, int numPolys,
@@ -293,6 +301,8 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     if (rp.max_depth < 0 || rp.max_depth > GPT_MAX_DEPTH)
         return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
     if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 64;
+    if (rp.passes_in_flight <= 0) rp.passes_in_flight = 1;
+    if (rp.passes_in_flight > 64) rp.passes_in_flight = 64;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -303,6 +313,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     gpt_scene* s = new gpt_scene();
     s->device = device;
     s->params = rp;
+    if (const char* e = getenv("GPT_REFILL_BELOW")) s->refill_below = (unsigned)std::max(1, std::min(64, atoi(e)));
     gpt_status st = GPT_OK;
     do {
         if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -340,6 +351,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         gptkd::Tree tree;
         gptkd::BuildParams bp;
         bp.small_threshold = rp.kd_small_threshold;
+        if (const char* e = getenv("GPT_KD_COST")) bp.traversal_cost = (float)atof(e);
         gptkd::build(verts.data(), numPolys, bp, tree);
         s->n_nodes = (int)tree.nodes.size();
         s->n_refs = (int)tree.refs.size();
@@ -415,7 +427,10 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
     if (st) return st;
     if (numPixels != s->numPixels) {
         if ((st = free_pixel_buffers(s))) return st;
-        const size_t n = (size_t)numPixels;
+        int batch = s->params.passes_in_flight;
+        while (batch > 1 && (long long)batch * numPixels > (1ll << 30)) batch--;
+        if ((long long)numPixels > (1ll << 30)) return fail(GPT_ERR_TOO_LARGE, "too many pixels");
+        const size_t n = (size_t)numPixels * (size_t)batch;
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipMalloc((void**)&s->d_ray_o[k], n * sizeof(float4)));
             HIP_TRY(hipMalloc((void**)&s->d_ray_d[k], n * sizeof(float4)));
@@ -423,9 +438,10 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
         }
         HIP_TRY(hipMalloc((void**)&s->d_hit, n * sizeof(float2)));
         HIP_TRY(hipMalloc((void**)&s->d_pass, n * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&s->d_image, n * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&s->d_pass3, n * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s->d_image, (size_t)numPixels * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&s->d_pass3, (size_t)numPixels * 3 * sizeof(float)));
         s->numPixels = numPixels;
+        s->batch = batch;
     }
     HIP_TRY(hipMemsetAsync(s->d_image, 0, (size_t)numPixels * sizeof(float4), s->stream));
     HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
@@ -440,7 +456,7 @@ gpt_status gpt_render_pass(gpt_scene* s, const Camera* cam, int counter, float* 
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
     HIP_TRY(hipSetDevice(s->device));
-    if ((st = enqueue_pass(s, cam, counter, host_pixels ? s->d_pass3 : nullptr))) return st;
+    if ((st = enqueue_batch(s, cam, counter, 1, host_pixels ? s->d_pass3 : nullptr))) return st;
     if (host_pixels) {
         HIP_TRY(hipMemcpyAsync(host_pixels, s->d_pass3, (size_t)s->numPixels * 3 * sizeof(float),
                                hipMemcpyDeviceToHost, s->stream));
@@ -453,8 +469,9 @@ gpt_status gpt_render_range(gpt_scene* s, const Camera* cam, int counter_begin, 
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
     HIP_TRY(hipSetDevice(s->device));
-    for (int c = counter_begin; c < counter_end; c++) {
-        if ((st = enqueue_pass(s, cam, c, nullptr))) return st;
+    for (int c = counter_begin; c < counter_end; c += s->batch) {
+        const int P = std::min(s->batch, counter_end - c);
+        if ((st = enqueue_batch(s, cam, c, P, nullptr))) return st;
         if (s->profile && s->ev_used > 8192) {
             HIP_TRY(hipStreamSynchronize(s->stream));
             if ((st = collect_events(s))) return st;
@@ -534,6 +551,7 @@ gpt_status gpt_get_stats(gpt_scene* s, gpt_stats* out) {
     out->passes = s->passes;
     out->kd_nodes_visited = h[GPT_STAT_KD_NODES];
     out->kd_tris_tested = h[GPT_STAT_KD_TRIS];
+    out->hits = h[GPT_STAT_HITS];
     out->device_ms_trace = s->ms_trace;
     out->device_ms_total = s->ms_total;
     out->trace_launches = s->trace_launches;
@@ -559,7 +577,7 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     unsigned* counts = s->d_counters;
     unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
-    gptk_camera(s->stream, pixel_grid(N), &cp, N, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0],
+    gptk_camera(s->stream, pixel_grid(N), &cp, N, 1, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0],
                 s->d_pass, counts);
     const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
     // statistics are not touched by this query: use a scratch copy of the stats words
@@ -568,7 +586,7 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     HIP_TRY(hipMemsetAsync(scratch_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
     const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
     gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit, counts, work,
-                   scratch_stats, s->d_spill, s->spill_stride);
+                   scratch_stats, s->d_spill, s->spill_stride, s->refill_below);
     HIP_TRY(hipGetLastError());
     std::vector<float> h((size_t)N * 2);
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit, h.size() * 4, hipMemcpyDeviceToHost, s->stream));

@@ -16,6 +16,7 @@
 #define GPT_STAT_LIVE0 0                      // [GPT_MAX_DEPTH] live paths per depth
 #define GPT_STAT_KD_NODES (GPT_MAX_DEPTH + 0)
 #define GPT_STAT_KD_TRIS (GPT_MAX_DEPTH + 1)
+#define GPT_STAT_HITS (GPT_MAX_DEPTH + 2)     // closest-hit queries that found something
 #define GPT_STAT_WORDS (GPT_MAX_DEPTH + 8)
 
 struct DevGeometry {

@@ -64,24 +64,29 @@ __device__ __forceinline__ Mat load_material(const float4* __restrict__ mats, in
 }
 
 // ---------------------------------------------------------------------------
-// k_camera: one primary ray per pixel; queue slot i holds pixel i.
+// k_camera: one primary ray per (pass, pixel).  A launch covers `numPasses`
+// consecutive pass counters at once; queue slot i holds pixel i % numPixels of
+// pass i / numPixels.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels, uint32_t seed,
+__global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels, int numPasses, uint32_t seed0,
                                                       float4* __restrict__ ray_o,
                                                       float4* __restrict__ ray_d,
                                                       float4* __restrict__ thr,
                                                       float4* __restrict__ pass_rgb,
                                                       unsigned* __restrict__ counts) {
-    const int stride = gridDim.x * GPT_BLOCK;
-    for (int i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < numPixels; i += stride) {
+    const unsigned total = (unsigned)numPixels * (unsigned)numPasses;
+    const unsigned stride = gridDim.x * GPT_BLOCK;
+    for (unsigned i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < total; i += stride) {
+        const unsigned pass = i / (unsigned)numPixels;
+        const int pixel = (int)(i - pass * (unsigned)numPixels);
         V3 o, d;
-        camera_ray(cam, i, seed, o, d);
-        ray_o[i] = make_float4(o.x, o.y, o.z, __int_as_float(i));
+        camera_ray(cam, pixel, seed0 + pass, o, d);
+        ray_o[i] = make_float4(o.x, o.y, o.z, __int_as_float(pixel));
         ray_d[i] = make_float4(d.x, d.y, d.z, __int_as_float(-1));   // medium: air
-        thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pass));
         pass_rgb[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = (unsigned)numPixels;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -90,7 +95,15 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels,
 // a per-thread column of a global buffer and come back when the LDS part runs
 // empty.  Depth never exceeds the tree's depth, which sizes the spill buffer.
 // ---------------------------------------------------------------------------
+#ifndef KD_LDS_N
 #define KD_LDS_N 8
+#endif
+#ifndef KD_FETCH_CHUNK
+#define KD_FETCH_CHUNK 512u   // rays a wave takes from the global queue per atomic
+#endif
+#ifndef KD_WAVES_PER_EU
+#define KD_WAVES_PER_EU 6
+#endif
 
 struct DevStack {
     uint32_t* lds;          // this thread's column: lds[(3*e + c) * GPT_BLOCK]
@@ -132,29 +145,37 @@ struct DevStack {
 };
 
 // ---------------------------------------------------------------------------
-// k_intersect: closest hit for every live path of this depth.
-// Waves pull 64 queue slots at a time from a global work counter.
+// Closest hit among the ground plane and the spheres (traceRayKernel :509-533).
 // ---------------------------------------------------------------------------
-template <bool USE_KD, bool STATS>
-__global__ __launch_bounds__(GPT_BLOCK) void k_intersect(DevGeometry g, int depth,
-                                                         const float4* __restrict__ ray_o,
-                                                         const float4* __restrict__ ray_d,
-                                                         float2* __restrict__ hit,
-                                                         unsigned* __restrict__ counts,
-                                                         unsigned* __restrict__ work,
-                                                         unsigned long long* __restrict__ stats,
-                                                         uint32_t* __restrict__ spill, size_t spill_stride) {
-    __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
+__device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, float& bestT, int& prim) {
+    bestT = PT_T_START;
+    prim = PT_PRIM_MISS;
+    if (g.ground_enabled) {
+        const float t = ground_t(g.ground_elevation, o, d);
+        if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
+    }
+    for (int s = 0; s < g.n_spheres; s++) {
+        const float4 sp = g.spheres[s];
+        const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
+        if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_intersect_brute: closest hit with the reference's loop over every triangle
+// (:536-557).  Waves pull 64 queue slots at a time from a global work counter.
+// ---------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, int depth,
+                                                               const float4* __restrict__ ray_o,
+                                                               const float4* __restrict__ ray_d,
+                                                               float2* __restrict__ hit,
+                                                               unsigned* __restrict__ counts,
+                                                               unsigned* __restrict__ work,
+                                                               unsigned long long* __restrict__ stats) {
     const unsigned n = counts[depth];
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
-
-    DevStack st;
-    st.lds = s_stack + threadIdx.x;
-    st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
-    st.spill_stride = spill_stride;
-    st.reset();
-
-    uint32_t cNodes = 0, cTris = 0;
+    uint32_t cTris = 0, cHits = 0;
     const unsigned lane = lane_id();
     for (;;) {
         const unsigned base = wave_fetch(&work[depth], 64u);
@@ -165,38 +186,142 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect(DevGeometry g, int dept
             const float4 rd = ray_d[i];
             const V3 o = v3(ro.x, ro.y, ro.z);
             const V3 d = v3(rd.x, rd.y, rd.z);
-
-            float bestT = PT_T_START;
-            int prim = PT_PRIM_MISS;
-            if (g.ground_enabled) {
-                const float t = ground_t(g.ground_elevation, o, d);
-                if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
-            }
-            for (int s = 0; s < g.n_spheres; s++) {
-                const float4 sp = g.spheres[s];
-                const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
-                if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
-            }
+            float bestT;
+            int prim;
+            analytic_hits(g, o, d, bestT, prim);
             if (g.n_tris > 0) {
                 float bt = bestT;
                 int bi = -1;
-                if (USE_KD) kd_closest_hit<DevStack, STATS>(g.kd, o, d, bt, bi, st, cNodes, cTris);
-                else brute_closest_hit<STATS>(g.kd.tris, g.n_tris, o, d, bt, bi, cTris);
+                brute_closest_hit<STATS>(g.kd.tris, g.n_tris, o, d, bt, bi, cTris);
                 if (bi >= 0) { bestT = bt; prim = bi; }
             }
             hit[i] = make_float2(bestT, __int_as_float(prim));
+            if (STATS && prim != PT_PRIM_MISS) cHits++;
         }
     }
     if (STATS) {
-        atomicAdd(&stats[GPT_STAT_KD_NODES], (unsigned long long)cNodes);
+        atomicAdd(&stats[GPT_STAT_HITS], (unsigned long long)cHits);
         atomicAdd(&stats[GPT_STAT_KD_TRIS], (unsigned long long)cTris);
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_shade: medium + BSDF for every live path, compaction into the next queue.
+// k_intersect_kd: closest hit with kd-tree traversal.
+//
+// Rays differ widely in traversal length (most miss the mesh's box at once, a
+// few walk hundreds of nodes), so a wave does not own a fixed set of 64 rays.
+// Each lane holds a resumable traversal cursor; the wave alternates between
+//   refill:   idle lanes take the next rays of the global work queue (one
+//             atomic per wave for all idle lanes: ballot + prefix count), test
+//             ground and spheres, and either finish at once (ray misses the
+//             root box) or start a traversal;
+//   traverse: lanes advance leaf by leaf until fewer than `refill_below` lanes
+//             are still busy, then the wave goes back to refill.
+// Once the queue is drained the remaining lanes simply run to completion.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed,
+template <bool STATS>
+__global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(DevGeometry g, int depth,
+                                                            const float4* __restrict__ ray_o,
+                                                            const float4* __restrict__ ray_d,
+                                                            float2* __restrict__ hit,
+                                                            unsigned* __restrict__ counts,
+                                                            unsigned* __restrict__ work,
+                                                            unsigned long long* __restrict__ stats,
+                                                            uint32_t* __restrict__ spill, size_t spill_stride,
+                                                            unsigned refill_below) {
+    __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
+    const unsigned n = counts[depth];
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
+
+    KdCursor<DevStack, STATS> cur;
+    cur.st.lds = s_stack + threadIdx.x;
+    cur.st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
+    cur.st.spill_stride = spill_stride;
+    cur.st.reset();
+
+    uint32_t cNodes = 0, cTris = 0, cHits = 0;
+    bool have = false;          // this lane holds an unfinished traversal
+    bool drained = false;       // wave-uniform: the work queue is exhausted
+    unsigned slot = 0;          // queue slot of the ray this lane is tracing
+    int prim0 = PT_PRIM_MISS;   // best among ground / spheres for that ray
+
+    // The wave takes rays from the global queue KD_FETCH_CHUNK at a time (one atomic on
+    // the shared counter per chunk) and hands them to idle lanes from that local range.
+    unsigned local_next = 0, local_end = 0;
+    for (;;) {
+        // ---- refill ----
+        while (!drained) {
+            const unsigned long long idle = __ballot(!have);
+            const unsigned cnt = (unsigned)__popcll(idle);
+            if (cnt == 0u || (64u - cnt) >= refill_below) break;
+            if (local_next >= local_end) {
+                const unsigned base = wave_fetch(&work[depth], KD_FETCH_CHUNK);
+                if (base >= n) { drained = true; break; }
+                local_next = base;
+                local_end = (base + KD_FETCH_CHUNK < n) ? base + KD_FETCH_CHUNK : n;
+            }
+            const unsigned avail = local_end - local_next;
+            const unsigned take = cnt < avail ? cnt : avail;
+            if (!have) {
+                const unsigned r = prefix_count(idle);
+                if (r < take) {
+                    const unsigned i = local_next + r;
+                    const float4 ro = ray_o[i];
+                    const float4 rd = ray_d[i];
+                    const V3 o = v3(ro.x, ro.y, ro.z);
+                    const V3 d = v3(rd.x, rd.y, rd.z);
+                    float bestT;
+                    int prim;
+                    analytic_hits(g, o, d, bestT, prim);
+                    if (cur.begin(g.kd, o, d, bestT)) {
+                        have = true;
+                        slot = i;
+                        prim0 = prim;
+                    } else {
+                        hit[i] = make_float2(bestT, __int_as_float(prim));
+                        if (STATS && prim != PT_PRIM_MISS) cHits++;
+                    }
+                }
+            }
+            local_next += take;
+        }
+        if (__ballot(have) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        // ---- traverse ----
+        while (have) {
+            if (cur.advance(g.kd, cNodes, cTris)) {
+                const int prim = cur.bestTri >= 0 ? cur.bestTri : prim0;
+                hit[slot] = make_float2(cur.bestT, __int_as_float(prim));
+                if (STATS && prim != PT_PRIM_MISS) cHits++;
+                have = false;
+            }
+            if (!drained && (unsigned)__popcll(__ballot(have)) < refill_below) break;
+        }
+    }
+    if (STATS) {
+        atomicAdd(&stats[GPT_STAT_KD_NODES], (unsigned long long)cNodes);
+        atomicAdd(&stats[GPT_STAT_KD_TRIS], (unsigned long long)cTris);
+        atomicAdd(&stats[GPT_STAT_HITS], (unsigned long long)cHits);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_shade: medium + BSDF for every live path, compaction into the next queue.
+//
+// Work is split statically (block-strided tiles of 256 paths).  Survivors are
+// not appended to the global queue one wave at a time -- a single hot counter
+// serialises at roughly 12 ns per atomic on MI355X -- but staged in LDS per
+// block: wave64 ballots + prefix counts place each survivor in the block's
+// staging area, and whenever 512 have gathered the block reserves 512 queue
+// slots with ONE atomic and writes them out as full coalesced rows.
+// ---------------------------------------------------------------------------
+#define SHADE_FLUSH 512
+#define SHADE_STAGE (SHADE_FLUSH + GPT_BLOCK)
+
+__global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
+                                                     int numPixels,
                                                      const float4* __restrict__ in_o,
                                                      const float4* __restrict__ in_d,
                                                      const float4* __restrict__ in_thr,
@@ -205,18 +330,24 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
                                                      float4* __restrict__ out_d,
                                                      float4* __restrict__ out_thr,
                                                      float4* __restrict__ pass_rgb,
-                                                     unsigned* __restrict__ counts,
-                                                     unsigned* __restrict__ work) {
+                                                     unsigned* __restrict__ counts) {
+    __shared__ float4 s_o[SHADE_STAGE];
+    __shared__ float4 s_d[SHADE_STAGE];
+    __shared__ float4 s_t[SHADE_STAGE];
+    __shared__ unsigned s_wave_cnt[GPT_BLOCK / 64];
+    __shared__ unsigned s_base;
+
     const unsigned n = counts[depth];
     const unsigned lane = lane_id();
-    unsigned* shade_head = work + GPT_MAX_DEPTH_SLOTS + depth;
-    for (;;) {
-        const unsigned base = wave_fetch(shade_head, 64u);
-        if (base >= n) break;
-        const unsigned i = base + lane;
+    const unsigned wave = threadIdx.x >> 6;
+    unsigned staged = 0;                        // block-uniform: survivors waiting in LDS
+    const unsigned stride = gridDim.x * GPT_BLOCK;
+    for (unsigned tile = blockIdx.x * GPT_BLOCK; tile < n; tile += stride) {
+        const unsigned i = tile + threadIdx.x;
         bool alive = false;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0), thr = v3(0, 0, 0);
         int pixel = 0, medium = -1;
+        unsigned pass = 0;
         if (i < n) {
             const float4 ro = in_o[i];
             const float4 rd = in_d[i];
@@ -227,6 +358,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
             thr = v3(th.x, th.y, th.z);
             pixel = __float_as_int(ro.w);
             medium = __float_as_int(rd.w);
+            pass = __float_as_uint(th.w);
             const float bestT = h.x;
             const int prim = __float_as_int(h.y);
 
@@ -257,40 +389,90 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
             V3 add;
             bool has_add;
             alive = shade_bounce(o, d, thr, medium, sa, ss, prim != PT_PRIM_MISS, bestT, nrm, m, matIndex,
-                                 pixel, depth, seed, sp, add, has_add);
+                                 pixel, depth, seed0 + pass, sp, add, has_add);
             if (has_add) {
-                float4 acc = pass_rgb[pixel];
+                const size_t slot = (size_t)pass * (size_t)numPixels + (size_t)pixel;
+                float4 acc = pass_rgb[slot];
                 acc.x += add.x; acc.y += add.y; acc.z += add.z;
-                pass_rgb[pixel] = acc;
+                pass_rgb[slot] = acc;
             }
         }
-        // ---- wave64 compaction: ballot, prefix count, one atomic per wave ----
+        // ---- block compaction into the LDS staging area ----
         const unsigned long long mask = __ballot(alive);
-        if (mask != 0ull) {
-            unsigned wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&counts[depth + 1], (unsigned)__popcll(mask));
-            wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
-            if (alive) {
-                const unsigned dst = wbase + prefix_count(mask);
-                out_o[dst] = make_float4(o.x, o.y, o.z, __int_as_float(pixel));
-                out_d[dst] = make_float4(d.x, d.y, d.z, __int_as_float(medium));
-                out_thr[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+        if (lane == 0) s_wave_cnt[wave] = (unsigned)__popcll(mask);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (unsigned w = 0; w < GPT_BLOCK / 64; w++) {
+            const unsigned c = s_wave_cnt[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if (alive) {
+            const unsigned pos = staged + before + prefix_count(mask);
+            s_o[pos] = make_float4(o.x, o.y, o.z, __int_as_float(pixel));
+            s_d[pos] = make_float4(d.x, d.y, d.z, __int_as_float(medium));
+            s_t[pos] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pass));
+        }
+        staged += total;
+        __syncthreads();
+        if (staged >= SHADE_FLUSH) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&counts[depth + 1], (unsigned)SHADE_FLUSH);
+            __syncthreads();
+            const unsigned base = s_base;
+#pragma unroll
+            for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += GPT_BLOCK) {
+                out_o[base + k] = s_o[k];
+                out_d[base + k] = s_d[k];
+                out_thr[base + k] = s_t[k];
             }
+            // move the remainder (< 256 entries) to the front
+            const unsigned rem = staged - SHADE_FLUSH;
+            float4 ko = make_float4(0, 0, 0, 0), kd_ = ko, kt = ko;
+            if (threadIdx.x < rem) {
+                ko = s_o[SHADE_FLUSH + threadIdx.x];
+                kd_ = s_d[SHADE_FLUSH + threadIdx.x];
+                kt = s_t[SHADE_FLUSH + threadIdx.x];
+            }
+            __syncthreads();
+            if (threadIdx.x < rem) {
+                s_o[threadIdx.x] = ko;
+                s_d[threadIdx.x] = kd_;
+                s_t[threadIdx.x] = kt;
+            }
+            staged = rem;
+            __syncthreads();
+        }
+    }
+    // ---- flush what is left ----
+    if (staged > 0) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&counts[depth + 1], staged);
+        __syncthreads();
+        const unsigned base = s_base;
+        for (unsigned k = threadIdx.x; k < staged; k += GPT_BLOCK) {
+            out_o[base + k] = s_o[k];
+            out_d[base + k] = s_d[k];
+            out_thr[base + k] = s_t[k];
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_finish: image += pass; optionally the pass alone as packed float3 for the
-// host (the reference's D2H copy, path_tracer_kernel.cu:869).
+// k_finish: image += pass for every pass of the batch, in counter order, so a
+// pixel's float sum is the one PathTracer::render builds (path_tracer.cpp:100-103).
+// Optionally the (single) pass alone as packed float3 for the host (the
+// reference's D2H copy, path_tracer_kernel.cu:869).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, const float4* __restrict__ pass_rgb,
+__global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPasses, const float4* __restrict__ pass_rgb,
                                                       float4* __restrict__ image, float* __restrict__ pass_out3) {
     const int stride = gridDim.x * GPT_BLOCK;
     for (int i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < numPixels; i += stride) {
-        const float4 p = pass_rgb[i];
         float4 a = image[i];
-        a.x += p.x; a.y += p.y; a.z += p.z; a.w += 1.0f;
+        float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < numPasses; k++) {
+            p = pass_rgb[(size_t)k * (size_t)numPixels + (size_t)i];
+            a.x += p.x; a.y += p.y; a.z += p.z; a.w += 1.0f;
+        }
         image[i] = a;
         if (pass_out3) {
             pass_out3[3 * (size_t)i + 0] = p.x;
@@ -349,32 +531,43 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_checksum(const uint32_t* __restri
 // ---------------------------------------------------------------------------
 extern "C" {
 
-void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, uint32_t seed, float4* ray_o,
-                 float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts) {
-    hipLaunchKernelGGL(k_camera, dim3(grid), dim3(GPT_BLOCK), 0, s, *cam, numPixels, seed, ray_o, ray_d, thr,
-                       pass_rgb, counts);
+void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, int numPasses, uint32_t seed0,
+                 float4* ray_o, float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts) {
+    hipLaunchKernelGGL(k_camera, dim3(grid), dim3(GPT_BLOCK), 0, s, *cam, numPixels, numPasses, seed0, ray_o, ray_d,
+                       thr, pass_rgb, counts);
 }
 
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
-                    unsigned long long* stats, uint32_t* spill, size_t spill_stride) {
-#define GPT_LAUNCH_INTERSECT(KD, ST)                                                                        \
-    hipLaunchKernelGGL((k_intersect<KD, ST>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d,   \
-                       hit, counts, work, stats, spill, spill_stride)
-    if (use_kd) { if (stats_on) GPT_LAUNCH_INTERSECT(true, true); else GPT_LAUNCH_INTERSECT(true, false); }
-    else { if (stats_on) GPT_LAUNCH_INTERSECT(false, true); else GPT_LAUNCH_INTERSECT(false, false); }
-#undef GPT_LAUNCH_INTERSECT
+                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below) {
+    if (use_kd) {
+        if (stats_on)
+            hipLaunchKernelGGL((k_intersect_kd<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
+                               counts, work, stats, spill, spill_stride, refill_below);
+        else
+            hipLaunchKernelGGL((k_intersect_kd<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
+                               counts, work, stats, spill, spill_stride, refill_below);
+    } else {
+        if (stats_on)
+            hipLaunchKernelGGL((k_intersect_brute<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d,
+                               hit, counts, work, stats);
+        else
+            hipLaunchKernelGGL((k_intersect_brute<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d,
+                               hit, counts, work, stats);
+    }
 }
 
-void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed,
-                const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
+                int numPixels, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed, in_o, in_d, in_thr, hit,
-                       out_o, out_d, out_thr, pass_rgb, counts, work);
+    (void)work;
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPixels, in_o, in_d, in_thr, hit,
+                       out_o, out_d, out_thr, pass_rgb, counts);
 }
 
-void gptk_finish(hipStream_t s, int grid, int numPixels, const float4* pass_rgb, float4* image, float* pass_out3) {
-    hipLaunchKernelGGL(k_finish, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, pass_rgb, image, pass_out3);
+void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
+                 float* pass_out3) {
+    hipLaunchKernelGGL(k_finish, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass_rgb, image, pass_out3);
 }
 
 void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,

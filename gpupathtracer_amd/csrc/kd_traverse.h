@@ -53,36 +53,53 @@ PT_HD void load_tri(const TriRec* tris, int idx, V3& a, V3& e1, V3& e2) {
 
 // Stack concept: void reset(); void push(uint32_t node, float tmin, float tmax);
 //                bool pop(uint32_t& node, float& tmin, float& tmax);
+//
+// KdCursor is a resumable traversal: begin() clips the ray against the root box,
+// advance() walks to the next leaf, tests its triangles and moves to the next
+// deferred interval; it returns true once nothing can beat the current best.
+// (The kernels interleave advance() calls of 64 rays per wave and hand finished
+// lanes new rays; the host harness simply loops.)
 template <class Stack, bool STATS>
-PT_HD void kd_closest_hit(const KdView& kd, V3 o, V3 d, float& bestT, int& bestTri, Stack& st,
-                          uint32_t& nodesVisited, uint32_t& trisTested) {
-    // ---- clip against the (padded) root box ----
-    float tmin = 0.0f, tmax = bestT;
-    {
+struct KdCursor {
+    V3 o, d, inv;
+    float tmin, tmax, bestT;
+    int bestTri;
+    uint32_t node;
+    Stack st;
+
+    // false: the ray cannot hit any triangle (it misses the padded root box).
+    PT_HD bool begin(const KdView& kd, V3 o_, V3 d_, float t_limit) {
+        o = o_; d = d_;
+        bestT = t_limit;
+        bestTri = -1;
+        tmin = 0.0f;
+        tmax = t_limit;
         const float oc[3] = {o.x, o.y, o.z};
         const float dc[3] = {d.x, d.y, d.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
             if (dc[a] != 0.0f) {
-                float inv = 1.0f / dc[a];
-                float ta = (lo - oc[a]) * inv, tb = (hi - oc[a]) * inv;
+                float iv = 1.0f / dc[a];
+                float ta = (lo - oc[a]) * iv, tb = (hi - oc[a]) * iv;
                 float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
                 tn -= PT_KD_REL_SLACK * fabsf(tn);
                 tf += PT_KD_REL_SLACK * fabsf(tf);
                 tmin = fmaxf(tmin, tn);
                 tmax = fminf(tmax, tf);
             } else if (!(oc[a] >= lo && oc[a] <= hi)) {
-                return;
+                return false;
             }
         }
-        if (!(tmin <= tmax)) return;
+        if (!(tmin <= tmax)) return false;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        node = 0;
+        st.reset();
+        return true;
     }
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t node = 0;
-    st.reset();
 
-    for (;;) {
+    // One leaf visit.  Returns true when the traversal is complete.
+    PT_HD bool advance(const KdView& kd, uint32_t& nodesVisited, uint32_t& trisTested) {
         KdNode w = kd.nodes[node];
         if (STATS) nodesVisited++;
         while ((w.w0 & 3u) != 3u) {
@@ -138,10 +155,24 @@ PT_HD void kd_closest_hit(const KdView& kd, V3 o, V3 d, float& bestT, int& bestT
         }
         // ---- next deferred interval that can still hold a closer (or equal) hit ----
         do {
-            if (!st.pop(node, tmin, tmax)) return;
+            if (!st.pop(node, tmin, tmax)) return true;
         } while (bestT < tmin);
         tmax = fminf(tmax, bestT);
+        return false;
     }
+};
+
+template <class Stack, bool STATS>
+PT_HD void kd_closest_hit(const KdView& kd, V3 o, V3 d, float& bestT, int& bestTri, Stack& st,
+                          uint32_t& nodesVisited, uint32_t& trisTested) {
+    KdCursor<Stack, STATS> c;
+    c.st = st;
+    if (c.begin(kd, o, d, bestT)) {
+        while (!c.advance(kd, nodesVisited, trisTested)) {}
+        bestT = c.bestT;
+        bestTri = c.bestTri;
+    }
+    st = c.st;
 }
 
 // The reference's loop itself (:536-557) over the same triangle records.

@@ -60,10 +60,10 @@ CAMERA_DTYPE = np.dtype({
 # gpt_render_params (include/gpt.h)
 RENDER_PARAMS_DTYPE = np.dtype({
     "names": ["max_depth", "ray_bias", "min_ray_weight", "ground_elevation", "ground_enabled",
-              "row_stride_is_width", "use_kdtree", "kd_small_threshold", "reserved"],
+              "row_stride_is_width", "use_kdtree", "kd_small_threshold", "passes_in_flight", "reserved"],
     "formats": [np.int32, np.float32, np.float64, np.float32, np.int32, np.int32, np.int32,
-                np.int32, (np.int32, (7,))],
-    "offsets": [0, 4, 8, 16, 20, 24, 28, 32, 36],
+                np.int32, np.int32, (np.int32, (6,))],
+    "offsets": [0, 4, 8, 16, 20, 24, 28, 32, 36, 40],
     "itemsize": 64,
 })
 

@@ -163,7 +163,11 @@ typedef struct gpt_render_params {
      * 1: kd-tree traversal returning the same hit as that loop.               */
     int    use_kdtree;
     int    kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64) */
-    int    reserved[7];
+    /* Passes traced together by gpt_render_range: every kernel launch covers the
+     * live paths of this many consecutive pass counters (default 8).  Results do
+     * not depend on it. */
+    int    passes_in_flight;
+    int    reserved[6];
 } gpt_render_params;
 
 void gpt_render_params_default(gpt_render_params* p);
@@ -218,6 +222,7 @@ typedef struct gpt_stats {
     uint64_t passes;
     uint64_t kd_nodes_visited;    /* only counted when built with stats on     */
     uint64_t kd_tris_tested;
+    uint64_t hits;                /* closest-hit queries that found a primitive (same build) */
     double   device_ms_trace;     /* HIP-event time of the intersect kernels   */
     double   device_ms_total;     /* HIP-event time of whole passes            */
     uint64_t trace_launches;

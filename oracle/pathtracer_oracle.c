@@ -498,7 +498,7 @@ int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const S
     for (int rayDepth = 0; rayDepth < P->max_depth; rayDepth++) {
         if (live_at_depth) live_at_depth[rayDepth] = numActive;
         total += numActive;
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 8)
         for (int a = 0; a < numActive; a++) {
             int k = activePixels[a];
             int pix = pixel_ids ? pixel_ids[k] : k;

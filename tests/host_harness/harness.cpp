@@ -109,6 +109,8 @@ static Mat to_mat(const Material& m) {
     return r;
 }
 
+static uint64_t g_hist[64]; static uint64_t g_maxnodes; static float g_worst[8];
+void hh_hist(uint64_t* out, uint64_t* maxnodes, float* worst) { memcpy(out, g_hist, sizeof(g_hist)); *maxnodes = g_maxnodes; memcpy(worst, g_worst, 32); memset(g_hist,0,sizeof(g_hist)); g_maxnodes=0; }
 int64_t hh_render_pass(void* tree_or_null, int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
                        const int32_t* pixel_ids, int n, int counter, const Camera* cam,
                        const gpt_render_params* rp, float* out_rgb, int32_t* first_prim, float* first_t) {
@@ -149,7 +151,10 @@ int64_t hh_render_pass(void* tree_or_null, int numPolys, const Poly* polys, int 
             }
             {
                 int bi = -1; uint32_t c0 = 0, c1 = 0; float bt = bestT;
-                if (h) { HostStack st; st.max_sp = 0; kd_closest_hit<HostStack, false>(h->view, o, d, bt, bi, st, c0, c1); }
+                if (h) { HostStack st; st.max_sp = 0; kd_closest_hit<HostStack, true>(h->view, o, d, bt, bi, st, c0, c1);
+                    int b = 0; while ((1u << b) <= c0 && b < 63) b++;
+                    #pragma omp critical
+                    { g_hist[b]++; if (c0 > g_maxnodes) { g_maxnodes = c0; g_worst[0]=o.x; g_worst[1]=o.y; g_worst[2]=o.z; g_worst[3]=d.x; g_worst[4]=d.y; g_worst[5]=d.z; g_worst[6]=(float)depth; g_worst[7]=(float)c1; } } }
                 else brute_closest_hit<false>(recs.data(), numPolys, o, d, bt, bi, c1);
                 if (bi >= 0) { bestT = bt; prim = bi; }
             }
