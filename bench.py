@@ -52,14 +52,6 @@ def build_workload(name, subdiv):
     return spheres, polys
 
 
-class CudaArray:
-    """Minimal __cuda_array_interface__ holder so torch can wrap the scene's image in place."""
-
-    def __init__(self, ptr, n_floats):
-        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False),
-                                         "version": 2}
-
-
 def cpu_baseline(spheres, polys, cam, depth, target_seconds=12.0):
     """The oracle (reference algorithm, brute-force triangle loop) on a strided pixel subset."""
     import oracle_lib as O
@@ -95,21 +87,21 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cow_heavy")
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=8, help="passes traced together per launch")
+    ap.add_argument("--batch", type=int, default=32, help="passes traced together per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from gpupathtracer_amd import api
+    from gpupathtracer_amd import api, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +135,7 @@ def main():
         torch.cuda.synchronize()
 
     # rank r owns pass counters [r*(K+W), (r+1)*(K+W)): disjoint, independently seeded samples
-    base = rank * (K + W)
+    base, _ = sharding.weak_range(K + W, rank)
 
     # ---- untimed: kd work per path-bounce (instrumented kernel), then warm-up ----
     scene.set_profiling(time_kernels=False, count_kd_work=True)
@@ -158,15 +150,13 @@ def main():
     scene.reset(n_pix)
     scene.set_profiling(time_kernels=True, count_kd_work=False)
 
-    img_ptr, img_bytes = scene.accum_device_ptr()
-    image = torch.as_tensor(CudaArray(img_ptr, img_bytes // 4), device=torch.device("cuda", local_rank))
+    image = sharding.scene_image_tensor(scene, torch.device("cuda", local_rank))
 
     # ---- timed region: exactly K passes per rank + the sum-reduce of the images ----
     barrier()
     t0 = time.perf_counter()
     scene.render_range(cam, base + W, base + W + K, sync=True)
-    if distributed:
-        dist.all_reduce(image, op=dist.ReduceOp.SUM)
+    sharding.sum_images(image)
     barrier()
     elapsed = time.perf_counter() - t0
 

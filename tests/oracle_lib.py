@@ -152,3 +152,27 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def kd_build(verts, small_threshold=64, traversal_cost=1.0):
+    """Oracle kd-tree builder (oracle/kdtree_oracle.c)."""
+    L = lib()
+    L.orc_kd_build.restype = ctypes.c_int
+    L.orc_kd_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                               ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    L.orc_kd_free.argtypes = [ctypes.c_void_p]
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+    pn, pr = ctypes.c_void_p(), ctypes.c_void_p()
+    nn, nr, md = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    bounds = np.zeros(6, dtype=np.float32)
+    rc = L.orc_kd_build(_ptr(verts), verts.shape[0], int(small_threshold), ctypes.c_float(traversal_cost),
+                        ctypes.byref(pn), ctypes.byref(nn), ctypes.byref(pr), ctypes.byref(nr),
+                        _ptr(bounds), ctypes.byref(md))
+    assert rc == 0
+    nodes = np.ctypeslib.as_array(ctypes.cast(pn, ctypes.POINTER(ctypes.c_uint32)), shape=(nn.value, 2)).copy()
+    refs = (np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_int32)), shape=(max(nr.value, 1),)).copy()[:nr.value])
+    L.orc_kd_free(pn)
+    L.orc_kd_free(pr)
+    return {"nodes": nodes, "refs": refs, "bounds": bounds, "max_depth": md.value}

@@ -1,0 +1,208 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gpt.h declares, and its
+host-side functions (no GPU compute) behave like the reference's host code."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import objref
+import oracle_lib as O
+import scenes as S
+from gpupathtracer_amd import _lib, api, meshes
+from gpupathtracer_amd.types import (AS_DTYPE, CAMERA_DTYPE, MATERIAL_DTYPE, MEDIUM_DTYPE, POLY_DTYPE,
+                                     RAY_DTYPE, RENDER_PARAMS_DTYPE, SPHERE_DTYPE)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "gpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(gpt_[a-z0-9_]+|launchKernel)\s*\(", text))
+    return {n for n in names if not n.endswith("_")}
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = _lib.lib()
+    declared = header_functions()
+    assert "launchKernel" in declared and "gpt_scene_create" in declared and len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), "libgpt_hip.so does not export " + name
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_pod_layouts_match_the_reference_structs():
+    # sizes from SURVEY of the CUDA layouts: Camera 64 (float2 8-aligned), Sphere 76, Poly 120, ...
+    assert AS_DTYPE.itemsize == 16 and MEDIUM_DTYPE.itemsize == 20 and MATERIAL_DTYPE.itemsize == 60
+    assert SPHERE_DTYPE.itemsize == 76 and POLY_DTYPE.itemsize == 120 and RAY_DTYPE.itemsize == 24
+    assert CAMERA_DTYPE.itemsize == 64 and CAMERA_DTYPE.fields["fov"][1] == 48
+    assert RENDER_PARAMS_DTYPE.itemsize == 64
+
+
+def test_render_params_defaults_are_the_reference_defines():
+    p = api.render_params()[0]
+    assert p["max_depth"] == 30                                  # MAX_TRACE_DEPTH
+    assert p["ray_bias"] == np.float32(0.0002)                    # RAY_BIAS_DISTANCE
+    assert p["min_ray_weight"] == 0.00001                         # MIN_RAY_WEIGHT (double)
+    assert p["ground_elevation"] == np.float32(-0.8)              # HARD_CODED_GROUND_ELEVATION
+    assert p["ground_enabled"] == 1 and p["use_kdtree"] == 1 and p["kd_small_threshold"] == 64
+
+
+def test_default_scene_and_presets_match_python_table():
+    s = api.default_scene()
+    assert np.all(s == S.default_spheres())
+    for name, m in S.MATERIALS.items():
+        got = api.material_preset(name)
+        assert got == np.array(m, dtype=MATERIAL_DTYPE), name
+    with pytest.raises(api.GptError):
+        api.material_preset("unobtainium")
+
+
+@pytest.mark.parametrize("wh", [(512, 512), (1920, 1080), (3840, 2160), (128, 96)])
+def test_orbit_camera_matches_python_restatement(wh):
+    w, h = wh
+    assert api.default_camera(w, h) == S.orbit_camera(w, h)
+    a = api.orbit_camera(w, h, fovx=60.0, yaw=0.7, pitch=-0.2, radius=2.5, aperture=0.0, center=(0.1, 0.5, -0.3))
+    b = S.orbit_camera(w, h, fovx=60.0, yaw=0.7, pitch=-0.2, radius=2.5, aperture=0.0, center=(0.1, 0.5, -0.3))
+    assert a == b
+
+
+def test_default_camera_values():
+    c = api.default_camera(512, 512)
+    assert np.allclose(c["position"], [0, 1.18208, 3.82135], atol=1e-5)
+    assert c["focalDistance"] == 4 and c["apertureRadius"] == np.float32(0.04) and c["fov"][0] == 45
+
+
+def test_tonemap_matches_oracle_and_ppm_pfm_roundtrip(tmp_path):
+    rng = np.random.default_rng(3)
+    w, h, passes = 37, 23, 7
+    img = (rng.random((w * h, 3), dtype=np.float32) * 12).astype(np.float32)
+    img[5] = (np.nan, 0.0, 1e9)
+    got = api.tonemap_8bit(img, passes)
+    assert np.array_equal(got, O.tonemap_8bit(img, passes))
+    ppm = str(tmp_path / "a.ppm")
+    api.write_ppm(ppm, img, w, h, passes)
+    raw = open(ppm, "rb").read()
+    header = b"P6\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(header) and raw[len(header):] == got.tobytes()   # row 0 first = top row
+    pfm = str(tmp_path / "a.pfm")
+    api.write_pfm(pfm, img, w, h, passes)
+    raw = open(pfm, "rb").read()
+    header = b"PF\n%d %d\n-1.0\n" % (w, h)
+    assert raw.startswith(header)
+    data = np.frombuffer(raw[len(header):], dtype="<f4").reshape(h, w, 3)[::-1]   # PFM rows bottom-up
+    want = (img / np.float32(passes)).reshape(h, w, 3)
+    assert np.array_equal(data[~np.isnan(want)], want[~np.isnan(want)])
+    with pytest.raises(api.GptError):
+        api.write_ppm(str(tmp_path / "nodir" / "x.ppm"), img, w, h, passes)
+
+
+OBJ_TEXT = """# comment
+mtllib x.mtl
+g default
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0.5
+v 0.5 0.5 1
+vt 0 0
+vn 0 0 1
+vn 0 1 0
+vn 1 0 0
+
+f 1//1 2//2 3//3
+f 1/1/2 3/1/2 4/1/2
+f 1 2 5
+f 1//3 2//3 3//3 4//3
+f 2 3 5 4
+"""
+
+
+def test_obj_loader_semantics(tmp_path):
+    path = str(tmp_path / "t.obj")
+    open(path, "w").write(OBJ_TEXT)
+    polys, bbox = api.obj_load(path, S.MATERIALS["marble"])
+    v, n, bb = objref.triangles(path)
+    assert polys.size == 5
+    got_v = np.concatenate([polys["p0"], polys["p1"], polys["p2"]], axis=1)
+    assert np.array_equal(got_v, v)
+    assert np.array_equal(polys["n"][[0, 1, 3]], n[[0, 1, 3]])
+    assert np.array_equal(polys["n"][0], [0, 0, 1]) and np.array_equal(polys["n"][1], [0, 1, 0])
+    # faces without normals get the geometric normal (unit length)
+    assert np.allclose(np.linalg.norm(polys["n"][[2, 4]], axis=1), 1, atol=1e-6)
+    assert np.allclose(polys["n"][[2, 4]], n[[2, 4]], atol=1e-6)
+    # quads keep only their first three vertices
+    assert np.array_equal(polys["p2"][3], [1, 1, 0])
+    assert np.array_equal(bbox, [0, 0, 0, 1, 1, 1]) and np.array_equal(bb, bbox)
+    assert np.all(polys["position"] == np.array([0, -0.8, 0], np.float32))
+    assert polys["material"][0] == np.array(S.MATERIALS["marble"], MATERIAL_DTYPE)
+
+
+def test_obj_loader_errors(tmp_path):
+    with pytest.raises(api.GptError) as e:
+        api.obj_load(str(tmp_path / "missing.obj"))
+    assert "could not be found" in str(e.value)
+    bad = str(tmp_path / "bad.obj")
+    open(bad, "w").write("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
+    with pytest.raises(api.GptError):
+        api.obj_load(bad)
+    dbl = str(tmp_path / "dbl.obj")
+    open(dbl, "w").write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1  2 3\n")   # double space -> empty token -> index -1
+    with pytest.raises(api.GptError):
+        api.obj_load(dbl)
+
+
+# pins recorded from the reference's own loader for its bundled meshes
+REF_MESH_PINS = {
+    "box": (12, (-0.8, -0.8, -0.8, 0.8, 0.8, 0.8)),
+    "cow": (5804, (-0.792737, -0.038824, -0.303377, 1.06952, 1.10178, 0.303377)),
+    "diamond": (110, (-0.784783, 1.5719, -2.66099, 0.561428, 2.91262, -0.976664)),
+    "coil": (492, (-0.916164, 6.13932, -1.13891, 2.74781, 10.6133, 2.67188)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(REF_MESH_PINS))
+def test_reference_meshes_load_with_recorded_counts(reference_root, name):
+    polys, bbox = api.obj_load(os.path.join(reference_root, name + ".obj"))
+    faces, want_bbox = REF_MESH_PINS[name]
+    assert polys.size == faces
+    assert np.allclose(bbox, want_bbox, rtol=0, atol=1e-5)
+    v, n, bb = objref.triangles(os.path.join(reference_root, name + ".obj"))
+    got_v = np.concatenate([polys["p0"], polys["p1"], polys["p2"]], axis=1)
+    assert np.array_equal(got_v, v) and np.array_equal(polys["n"], n)
+    av, an = meshes.load_asset(name)               # the bundled asset is exactly that data
+    assert np.array_equal(av, v) and np.array_equal(an, n)
+
+
+def test_cow_first_face_pin(reference_root):
+    polys, _ = api.obj_load(os.path.join(reference_root, "cow.obj"))
+    # face 0 is "f 3//1 4//2 2//3": p0 = vertex 3, normal = normal 1
+    assert np.allclose(polys["p0"][0], [0.429791987, 0.470970988, -0.149976999], atol=1e-7)
+    assert np.allclose(polys["n"][0], [0.442214012, -0.167945996, -0.881044984], atol=1e-7)
+
+
+def test_scene_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.GptError) as e:
+        api.Scene(api.default_scene())
+    assert e.value.status == 3          # GPT_ERR_NO_DEVICE: no silent CPU fallback
+
+
+def test_subdivision_is_watertight_and_deterministic():
+    v, n = meshes.load_asset("box")
+    v2, n2 = meshes.subdivide(v, n, 3)
+    assert v2.shape == (12 * 64, 9) and n2.shape == (12 * 64, 3)
+    a, b = meshes.subdivide(v, n, 3)
+    assert np.array_equal(a, v2) and np.array_equal(b, n2)
+    # every edge midpoint is shared bit-exactly: unique vertices of a closed cube surface
+    pts = np.unique(v2.reshape(-1, 3), axis=0)
+    assert pts.shape[0] == 6 * 8 * 8 + 2              # V = F/2 + 2 for a closed triangle mesh
+    # area is preserved
+    def area(t):
+        t = t.reshape(-1, 3, 3).astype(np.float64)
+        return np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum() / 2
+    assert abs(area(v2) - area(v)) < 1e-5

@@ -1,0 +1,107 @@
+"""CPU: the library's per-path arithmetic (pt_device.h, the code the HIP kernels call),
+compiled for the host by tests/host_harness, against the oracle.  Differences can only
+come from the transcendental policy (double-rounded sin/cos/log/exp vs glibc's float
+functions), so bounce counts agree and samples differ in the last bits only."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes as S
+from gpupathtracer_amd import meshes
+from gpupathtracer_amd.types import CAMERA_DTYPE, POLY_DTYPE, RENDER_PARAMS_DTYPE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(HERE, "host_harness", "libhh.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host_harness")])
+    L = ctypes.CDLL(so)
+    L.hh_tree_build.restype = ctypes.c_void_p
+    L.hh_tree_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    L.hh_tree_free.argtypes = [ctypes.c_void_p]
+    L.hh_render_pass.restype = ctypes.c_int64
+    return L
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def params(depth, stride=0):
+    r = np.zeros(1, RENDER_PARAMS_DTYPE)
+    r["max_depth"] = depth
+    r["ray_bias"] = 0.0002
+    r["min_ray_weight"] = 0.00001
+    r["ground_elevation"] = -0.8
+    r["ground_enabled"] = 1
+    r["row_stride_is_width"] = stride
+    return r
+
+
+def host_render(H, tree, polys, spheres, cam, counter, rp, ids):
+    n = ids.size
+    out = np.zeros((n, 3), np.float32)
+    fp = np.zeros(n, np.int32)
+    ft = np.zeros(n, np.float32)
+    cam = np.array(cam, CAMERA_DTYPE).reshape(1)
+    tot = H.hh_render_pass(ctypes.c_void_p(tree) if tree else None, polys.size, P(polys), spheres.size, P(spheres),
+                           P(ids), n, counter, P(cam), P(rp), P(out), P(fp), P(ft))
+    return out, tot, fp, ft
+
+
+def test_camera_rays_pinhole_bit_exact(H):
+    cam = S.orbit_camera(96, 64, aperture=0.0)
+    ids = np.arange(96 * 64, dtype=np.int32)
+    got = np.zeros((ids.size, 6), np.float32)
+    c = np.array(cam, CAMERA_DTYPE).reshape(1)
+    for stride in (0, 1):
+        H.hh_camera_rays(P(ids), ids.size, 9, P(c), stride, P(got))
+        ref = O.camera_rays(cam, 9, O.params(row_stride_is_width=stride))
+        assert np.array_equal(got.view(np.int32), ref.view(np.int32))
+
+
+@pytest.mark.parametrize("depth", [8, 30])
+def test_default_scene_logic_parity(H, depth):
+    w = 160
+    sph = S.default_spheres()
+    cam = S.orbit_camera(w, w)
+    ids = np.arange(w * w, dtype=np.int32)
+    nop = np.zeros(0, POLY_DTYPE)
+    for counter in (0, 5):
+        o = O.render_pass(sph, None, cam, counter, O.params(max_depth=depth), want_hits=True)
+        got, tot, fp, ft = host_render(H, None, nop, sph, cam, counter, params(depth), ids)
+        assert abs(tot - o["bounces"]) <= 4
+        assert (fp != o["hits"]["prim"]).mean() < 1e-4
+        rel = (np.abs(got - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=1)
+        assert (rel > 1e-4).mean() < 1e-3 and (rel > 0).mean() < 0.03
+
+
+def test_mesh_scene_logic_parity_kd_and_brute(H):
+    w = 96
+    sph = S.spheres_with(["steel", "greenGlass", "marble", "ketchup", "something", "glass", "gold", "white",
+                          "red", "orange", "purple", "lightBlue", "light", "green"])
+    dv, dn = meshes.load_asset("diamond")
+    dv = meshes.transform(dv, 0.8, (0.2, -2.2, 2.6))
+    polys = meshes.polys_from_triangles(dv, dn, S.MATERIALS["glass"])
+    cam = S.orbit_camera(w, w)
+    ids = np.arange(w * w, dtype=np.int32)
+    o = O.render_pass(sph, polys, cam, 1, O.params(max_depth=12), want_hits=True)
+    tree = H.hh_tree_build(P(np.ascontiguousarray(dv)), dv.shape[0], 64, 1.0)
+    try:
+        a, ta, fpa, fta = host_render(H, None, polys, sph, cam, 1, params(12), ids)
+        b, tb, fpb, ftb = host_render(H, tree, polys, sph, cam, 1, params(12), ids)
+    finally:
+        H.hh_tree_free(ctypes.c_void_p(tree))
+    # kd and brute force are the same function
+    assert np.array_equal(a, b) and ta == tb and np.array_equal(fpa, fpb) and np.array_equal(fta, ftb)
+    assert abs(ta - o["bounces"]) <= max(4, o["bounces"] // 500)
+    rel = (np.abs(a - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=1)
+    assert (rel > 1e-4).mean() < 4e-3
+    assert ((fpa >= 0) & (fpa < polys.size)).sum() > 50
