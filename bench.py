@@ -52,7 +52,7 @@ def build_workload(name, subdiv):
     return spheres, polys
 
 
-def cpu_baseline(spheres, polys, cam, depth, target_seconds=12.0):
+def cpu_baseline(spheres, polys, cam, depth, target_seconds=20.0):
     """The oracle (reference algorithm, brute-force triangle loop) on a strided pixel subset."""
     import oracle_lib as O
     w, h = int(cam["resolution"][0]), int(cam["resolution"][1])

@@ -117,11 +117,11 @@ struct gpt_scene {
     // geometry
     float4* d_spheres = nullptr;
     int* d_sphere_mat = nullptr;
-    TriRec* d_tris = nullptr;
+    TriRec* d_tris = nullptr;        // per triangle (brute force)
+    TriRec* d_leaf_tris = nullptr;   // per leaf reference (kd traversal)
     float4* d_tri_nm = nullptr;
     float4* d_mats = nullptr;
     pt::KdNode* d_nodes = nullptr;
-    int32_t* d_refs = nullptr;
     uint32_t* d_spill = nullptr;
     size_t spill_stride = 0;
     DevGeometry geom;
@@ -130,7 +130,7 @@ struct gpt_scene {
     // per-pixel / per-path buffers
     int numPixels = 0;
     int batch = 1;                           // passes traced together per launch
-    unsigned refill_below = 32;              // k_intersect_kd: refill a wave when fewer lanes are busy
+    unsigned refill_below = 48;              // k_intersect_kd: refill a wave when fewer lanes are busy
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};
@@ -339,7 +339,8 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             f[0] = p.p0.x; f[1] = p.p0.y; f[2] = p.p0.z;
             f[3] = p.p1.x - p.p0.x; f[4] = p.p1.y - p.p0.y; f[5] = p.p1.z - p.p0.z;   // edge1 (:230)
             f[6] = p.p2.x - p.p0.x; f[7] = p.p2.y - p.p0.y; f[8] = p.p2.z - p.p0.z;   // edge2 (:231)
-            f[9] = f[10] = f[11] = 0.0f;
+            memcpy(&f[9], &i, 4);   // triangle index
+            f[10] = f[11] = 0.0f;
             float* v = &verts[9 * (size_t)i];
             v[0] = p.p0.x; v[1] = p.p0.y; v[2] = p.p0.z;
             v[3] = p.p1.x; v[4] = p.p1.y; v[5] = p.p1.z;
@@ -353,17 +354,22 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         bp.small_threshold = rp.kd_small_threshold;
         if (const char* e = getenv("GPT_KD_COST")) bp.traversal_cost = (float)atof(e);
         gptkd::build(verts.data(), numPolys, bp, tree);
-        s->n_nodes = (int)tree.nodes.size();
         s->n_refs = (int)tree.refs.size();
         s->tree_depth = tree.max_depth;
+        // device storage: nodes clustered per 128-byte line, triangle records in leaf order
+        std::vector<gptkd::Node> dev_nodes;
+        gptkd::treelet_layout(tree, dev_nodes);
+        s->n_nodes = (int)dev_nodes.size();
+        std::vector<TriRec> leaf_recs(tree.refs.size());
+        for (size_t r = 0; r < tree.refs.size(); r++) leaf_recs[r] = recs[(size_t)tree.refs[r]];
 
         if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
         if ((st = upload(&s->d_sphere_mat, sph_mat.data(), sph_mat.size() * 4))) break;
         if ((st = upload(&s->d_tris, recs.data(), recs.size() * sizeof(TriRec)))) break;
         if ((st = upload(&s->d_tri_nm, nm.data(), nm.size() * 4))) break;
         if ((st = upload(&s->d_mats, mt.packed.data(), mt.packed.size() * 4))) break;
-        if ((st = upload(&s->d_nodes, tree.nodes.data(), tree.nodes.size() * 8))) break;
-        if ((st = upload(&s->d_refs, tree.refs.data(), tree.refs.size() * 4))) break;
+        if ((st = upload(&s->d_nodes, dev_nodes.data(), dev_nodes.size() * 8))) break;
+        if ((st = upload(&s->d_leaf_tris, leaf_recs.data(), leaf_recs.size() * sizeof(TriRec)))) break;
 
         s->spill_stride = (size_t)kTraceGrid * kBlock;
         const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
@@ -382,9 +388,9 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         g.n_tris = numPolys;
         g.tri_nm = s->d_tri_nm;
         g.mats = s->d_mats;
+        g.tris = s->d_tris;
         g.kd.nodes = s->d_nodes;
-        g.kd.refs = s->d_refs;
-        g.kd.tris = s->d_tris;
+        g.kd.leaf_tris = s->d_leaf_tris;
         float ext = 0;
         for (int k = 0; k < 3; k++) {
             g.kd.bmin[k] = tree.bounds[k];
@@ -410,8 +416,8 @@ gpt_status gpt_scene_destroy(gpt_scene* s) {
     hipSetDevice(s->device);
     if (s->stream) hipStreamSynchronize(s->stream);
     free_pixel_buffers(s);
-    void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_tri_nm, s->d_mats, s->d_nodes,
-                    s->d_refs, s->d_spill, s->d_counters, s->d_stats};
+    void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_tri_nm, s->d_mats, s->d_nodes,
+                    s->d_spill, s->d_counters, s->d_stats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
     if (s->stream) hipStreamDestroy(s->stream);

@@ -27,7 +27,8 @@ struct DevGeometry {
     const float4* tri_nm;      // (Poly.n.xyz, material index as int bits) per triangle
     const float4* mats;        // 4 x float4 per material:
                                //   (diffuse.rgb, ior) (specular.rgb, transmits) (emitted.rgb, sigma_s) (sigma_a.rgb, 0)
-    pt::KdView kd;             // nodes, refs, triangle records, root box, slack
+    const pt::TriRec* tris;    // one record per triangle, in Poly order (brute-force loop)
+    pt::KdView kd;             // nodes, leaf-ordered triangle records, root box, slack
     float ground_elevation;
     int ground_enabled;
 };

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
             if (g.n_tris > 0) {
                 float bt = bestT;
                 int bi = -1;
-                brute_closest_hit<STATS>(g.kd.tris, g.n_tris, o, d, bt, bi, cTris);
+                brute_closest_hit<STATS>(g.tris, g.n_tris, o, d, bt, bi, cTris);
                 if (bi >= 0) { bestT = bt; prim = bi; }
             }
             hit[i] = make_float2(bestT, __int_as_float(prim));
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_debug_intersect(DevGeometry g, co
         int bi = -1;
         if (g.n_tris > 0) {
             if (USE_KD) kd_closest_hit<DevStack, false>(g.kd, o, d, bt, bi, st, c0, c1);
-            else brute_closest_hit<false>(g.kd.tris, g.n_tris, o, d, bt, bi, c1);
+            else brute_closest_hit<false>(g.tris, g.n_tris, o, d, bt, bi, c1);
         }
         tri[i] = bi;
         t_out[i] = bt;

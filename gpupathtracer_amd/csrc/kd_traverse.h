@@ -21,13 +21,17 @@ namespace pt {
 struct KdNode { uint32_t w0, w1; };
 
 // Triangle record: a, edge1 = b - a, edge2 = c - a packed in three 16-byte
-// words: (a.x a.y a.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z - - -).
+// words: (a.x a.y a.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z index - -); `index` is
+// the triangle's position in the caller's Poly array (int bits).
 struct TriRec { float f[12]; };
 
+// Leaves do not point at triangles through an index list: the records of a
+// leaf's triangles are stored contiguously in leaf order (a triangle that several
+// leaves reference is stored once per leaf), so a leaf visit reads
+// count x 48 consecutive bytes.
 struct KdView {
     const KdNode* nodes;
-    const int32_t* refs;
-    const TriRec* tris;
+    const TriRec* leaf_tris;   // one record per (leaf, triangle) reference, leaf by leaf
     float bmin[3], bmax[3];
     float sigma;       // spatial slack: 2e-5 * largest extent of the root box
 };
@@ -44,11 +48,20 @@ PT_HD float bits_to_float(uint32_t u) {
 #endif
 }
 
-PT_HD void load_tri(const TriRec* tris, int idx, V3& a, V3& e1, V3& e2) {
-    const float* f = tris[idx].f;
+PT_HD int float_to_int_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_int(f);
+#else
+    int i; __builtin_memcpy(&i, &f, 4); return i;
+#endif
+}
+
+PT_HD int load_tri(const TriRec* tris, size_t slot, V3& a, V3& e1, V3& e2) {
+    const float* f = tris[slot].f;
     a = v3(f[0], f[1], f[2]);
     e1 = v3(f[3], f[4], f[5]);
     e2 = v3(f[6], f[7], f[8]);
+    return float_to_int_bits(f[9]);
 }
 
 // Stack concept: void reset(); void push(uint32_t node, float tmin, float tmax);
@@ -141,9 +154,8 @@ struct KdCursor {
         // ---- leaf ----
         const uint32_t first = w.w0 >> 2, count = w.w1;
         for (uint32_t k = 0; k < count; k++) {
-            const int idx = kd.refs[first + k];
             V3 a, e1, e2;
-            load_tri(kd.tris, idx, a, e1, e2);
+            const int idx = load_tri(kd.leaf_tris, (size_t)first + k, a, e1, e2);
             float t;
             if (STATS) trisTested++;
             if (triangle_t(a, e1, e2, o, d, t)) {
@@ -181,7 +193,7 @@ PT_HD void brute_closest_hit(const TriRec* tris, int n, V3 o, V3 d, float& bestT
                              uint32_t& trisTested) {
     for (int i = 0; i < n; i++) {
         V3 a, e1, e2;
-        load_tri(tris, i, a, e1, e2);
+        load_tri(tris, (size_t)i, a, e1, e2);
         float t;
         if (triangle_t(a, e1, e2, o, d, t)) {
             if (t > 0 && t < bestT) { bestT = t; bestTri = i; }

@@ -305,4 +305,49 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out) {
     }
 }
 
+void treelet_layout(const Tree& in, std::vector<Node>& out) {
+    const std::vector<Node>& src = in.nodes;
+    out.clear();
+    const uint32_t kPairsPerLine = 8;
+    const Node pad = {3u, 0u};                       // an empty leaf
+    // A "pair" is identified by the old index of its left node; the root is a pair of
+    // its own whose right slot is padding (old index UINT32_MAX marks "no node").
+    struct Pair { uint32_t left_old; bool is_root; };
+    std::deque<Pair> roots;                          // treelet roots still to be placed
+    roots.push_back({0u, true});
+    std::vector<uint32_t> new_index(src.size(), 0u); // old node index -> new node index
+    std::vector<std::pair<uint32_t, uint32_t>> placed;   // (old, new) in placement order
+    while (!roots.empty()) {
+        // start a new line
+        while (out.size() % (2 * kPairsPerLine) != 0) out.push_back(pad);
+        std::deque<Pair> frontier;
+        frontier.push_back(roots.front());
+        roots.pop_front();
+        uint32_t used = 0;
+        while (!frontier.empty() && used < kPairsPerLine) {
+            Pair p = frontier.front();
+            frontier.pop_front();
+            const uint32_t at = (uint32_t)out.size();
+            const uint32_t olds[2] = {p.left_old, p.is_root ? UINT32_MAX : p.left_old + 1u};
+            for (int k = 0; k < 2; k++) {
+                if (olds[k] == UINT32_MAX) { out.push_back(pad); continue; }
+                new_index[olds[k]] = at + (uint32_t)k;
+                placed.push_back({olds[k], at + (uint32_t)k});
+                out.push_back(src[olds[k]]);
+                if ((src[olds[k]].w0 & 3u) != 3u) frontier.push_back({src[olds[k]].w0 >> 2, false});
+            }
+            used++;
+        }
+        for (const Pair& p : frontier) roots.push_back(p);   // did not fit: new treelets
+    }
+    // rewrite child links
+    for (const auto& pn : placed) {
+        Node& n = out[pn.second];
+        if ((n.w0 & 3u) != 3u) {
+            const uint32_t old_left = n.w0 >> 2;
+            n.w0 = (new_index[old_left] << 2) | (n.w0 & 3u);
+        }
+    }
+}
+
 }  // namespace gptkd

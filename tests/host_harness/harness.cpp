@@ -23,7 +23,9 @@ struct HostStack {
 
 struct HTree {
     gptkd::Tree tree;
-    std::vector<TriRec> tris;
+    std::vector<gptkd::Node> dev_nodes;   // cache-line clustered order, as uploaded to the GPU
+    std::vector<TriRec> tris;             // per triangle
+    std::vector<TriRec> leaf_tris;        // per leaf reference
     KdView view;
 };
 
@@ -35,7 +37,8 @@ static void make_recs(const float* verts, int n, std::vector<TriRec>& out) {
         f[0] = v[0]; f[1] = v[1]; f[2] = v[2];
         f[3] = v[3] - v[0]; f[4] = v[4] - v[1]; f[5] = v[5] - v[2];
         f[6] = v[6] - v[0]; f[7] = v[7] - v[1]; f[8] = v[8] - v[2];
-        f[9] = f[10] = f[11] = 0;
+        memcpy(&f[9], &i, 4);
+        f[10] = f[11] = 0;
     }
 }
 
@@ -46,9 +49,11 @@ void* hh_tree_build(const float* verts, int n, int small_threshold, float traver
     gptkd::BuildParams bp; bp.small_threshold = small_threshold; bp.traversal_cost = traversal_cost;
     gptkd::build(verts, n, bp, h->tree);
     make_recs(verts, n, h->tris);
-    h->view.nodes = (const KdNode*)h->tree.nodes.data();
-    h->view.refs = h->tree.refs.data();
-    h->view.tris = h->tris.data();
+    gptkd::treelet_layout(h->tree, h->dev_nodes);
+    h->leaf_tris.resize(h->tree.refs.size());
+    for (size_t r = 0; r < h->tree.refs.size(); r++) h->leaf_tris[r] = h->tris[(size_t)h->tree.refs[r]];
+    h->view.nodes = (const KdNode*)h->dev_nodes.data();
+    h->view.leaf_tris = h->leaf_tris.data();
     float ext = 0;
     for (int k = 0; k < 3; k++) {
         h->view.bmin[k] = h->tree.bounds[k]; h->view.bmax[k] = h->tree.bounds[3 + k];

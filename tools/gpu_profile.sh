@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 8 --warmup 1 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --steps 32 --warmup 1 --no-cpu-baseline $*"
 
 run() {  # name, rocprof args...
   local name=$1; shift
@@ -24,5 +24,6 @@ run pmc_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU S
 run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE || exit 1
 run pmc_fetch --pmc FETCH_SIZE || exit 1
 run pmc_write --pmc WRITE_SIZE TCC_EA0_RDREQ_DRAM_sum || exit 1
+run pmc_rdreq --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum || echo "rdreq pass failed (optional)"
 run pmc_tcp --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum || echo "tcp pass failed (optional)"
 echo done
