@@ -22,6 +22,8 @@ class GptStats(ctypes.Structure):
         ("device_ms_trace", ctypes.c_double),
         ("device_ms_total", ctypes.c_double),
         ("trace_launches", ctypes.c_uint64),
+        ("kd_nodes_at_depth", ctypes.c_uint64 * 64),
+        ("kd_tris_at_depth", ctypes.c_uint64 * 64),
     ]
 
 

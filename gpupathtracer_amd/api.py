@@ -134,6 +134,8 @@ class Scene:
             "device_ms_trace": float(st.device_ms_trace),
             "device_ms_total": float(st.device_ms_total),
             "trace_launches": int(st.trace_launches),
+            "kd_nodes_at_depth": np.array(st.kd_nodes_at_depth[:], dtype=np.int64),
+            "kd_tris_at_depth": np.array(st.kd_tris_at_depth[:], dtype=np.int64),
         }
 
     def info(self):

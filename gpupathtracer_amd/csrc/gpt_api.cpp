@@ -31,7 +31,7 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
                     unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below);
 void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
-                int numPixels, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+                int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
@@ -119,6 +119,7 @@ struct gpt_scene {
     int* d_sphere_mat = nullptr;
     TriRec* d_tris = nullptr;        // per triangle (brute force)
     TriRec* d_leaf_tris = nullptr;   // per leaf reference (kd traversal)
+    int32_t* d_refs = nullptr;       // leaf -> triangle list (indexed layout only)
     float4* d_tri_nm = nullptr;
     float4* d_mats = nullptr;
     pt::KdNode* d_nodes = nullptr;
@@ -245,7 +246,7 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
             HIP_TRY(hipEventRecord(s->ev_pool[t1], s->stream));
             s->trace_pairs.push_back({t0, t1});
         }
-        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, N, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
+        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
                    s->d_hit, s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
     }
     gptk_finish(s->stream, pixel_grid(N), N, P, s->d_pass, s->d_image, pass3);
@@ -360,8 +361,16 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         std::vector<gptkd::Node> dev_nodes;
         gptkd::treelet_layout(tree, dev_nodes);
         s->n_nodes = (int)dev_nodes.size();
-        std::vector<TriRec> leaf_recs(tree.refs.size());
-        for (size_t r = 0; r < tree.refs.size(); r++) leaf_recs[r] = recs[(size_t)tree.refs[r]];
+        // Leaf triangles: records duplicated in leaf order while that copy stays well inside the
+        // 256 MiB Infinity Cache together with the rest of the scene; otherwise an index list
+        // into the per-triangle records (smaller footprint, one more dependent load).
+        bool leaf_order = tree.refs.size() * sizeof(TriRec) <= (size_t)160 << 20;
+        if (const char* e = getenv("GPT_LEAF_ORDER")) leaf_order = atoi(e) != 0;
+        std::vector<TriRec> leaf_recs;
+        if (leaf_order) {
+            leaf_recs.resize(tree.refs.size());
+            for (size_t r = 0; r < tree.refs.size(); r++) leaf_recs[r] = recs[(size_t)tree.refs[r]];
+        }
 
         if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
         if ((st = upload(&s->d_sphere_mat, sph_mat.data(), sph_mat.size() * 4))) break;
@@ -369,7 +378,11 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if ((st = upload(&s->d_tri_nm, nm.data(), nm.size() * 4))) break;
         if ((st = upload(&s->d_mats, mt.packed.data(), mt.packed.size() * 4))) break;
         if ((st = upload(&s->d_nodes, dev_nodes.data(), dev_nodes.size() * 8))) break;
-        if ((st = upload(&s->d_leaf_tris, leaf_recs.data(), leaf_recs.size() * sizeof(TriRec)))) break;
+        if (leaf_order) {
+            if ((st = upload(&s->d_leaf_tris, leaf_recs.data(), leaf_recs.size() * sizeof(TriRec)))) break;
+        } else {
+            if ((st = upload(&s->d_refs, tree.refs.data(), tree.refs.size() * 4))) break;
+        }
 
         s->spill_stride = (size_t)kTraceGrid * kBlock;
         const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
@@ -390,7 +403,8 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         g.mats = s->d_mats;
         g.tris = s->d_tris;
         g.kd.nodes = s->d_nodes;
-        g.kd.leaf_tris = s->d_leaf_tris;
+        g.kd.leaf_tris = leaf_order ? s->d_leaf_tris : s->d_tris;
+        g.kd.refs = leaf_order ? nullptr : s->d_refs;
         float ext = 0;
         for (int k = 0; k < 3; k++) {
             g.kd.bmin[k] = tree.bounds[k];
@@ -416,7 +430,7 @@ gpt_status gpt_scene_destroy(gpt_scene* s) {
     hipSetDevice(s->device);
     if (s->stream) hipStreamSynchronize(s->stream);
     free_pixel_buffers(s);
-    void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_tri_nm, s->d_mats, s->d_nodes,
+    void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_refs, s->d_tri_nm, s->d_mats, s->d_nodes,
                     s->d_spill, s->d_counters, s->d_stats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
@@ -558,6 +572,10 @@ gpt_status gpt_get_stats(gpt_scene* s, gpt_stats* out) {
     out->kd_nodes_visited = h[GPT_STAT_KD_NODES];
     out->kd_tris_tested = h[GPT_STAT_KD_TRIS];
     out->hits = h[GPT_STAT_HITS];
+    for (int d = 0; d < GPT_MAX_DEPTH; d++) {
+        out->kd_nodes_at_depth[d] = h[GPT_STAT_NODES_D0 + d];
+        out->kd_tris_at_depth[d] = h[GPT_STAT_TRIS_D0 + d];
+    }
     out->device_ms_trace = s->ms_trace;
     out->device_ms_total = s->ms_total;
     out->trace_launches = s->trace_launches;
@@ -594,13 +612,18 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit, counts, work,
                    scratch_stats, s->d_spill, s->spill_stride, s->refill_below);
     HIP_TRY(hipGetLastError());
-    std::vector<float> h((size_t)N * 2);
+    std::vector<float> h((size_t)N * 2), ro((size_t)N * 4);
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit, h.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(ro.data(), s->d_ray_o[0], ro.size() * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipFree(scratch_stats));
+    // queue slots are not in pixel order: each slot carries its pixel index
     for (int i = 0; i < N; i++) {
-        t[i] = h[2 * (size_t)i];
-        memcpy(&prim[i], &h[2 * (size_t)i + 1], 4);
+        int pixel;
+        memcpy(&pixel, &ro[4 * (size_t)i + 3], 4);
+        if (pixel < 0 || pixel >= N) return fail(GPT_ERR_HIP, "corrupt path queue");
+        t[pixel] = h[2 * (size_t)i];
+        memcpy(&prim[pixel], &h[2 * (size_t)i + 1], 4);
     }
     return GPT_OK;
 }

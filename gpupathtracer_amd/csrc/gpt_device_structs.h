@@ -17,7 +17,9 @@
 #define GPT_STAT_KD_NODES (GPT_MAX_DEPTH + 0)
 #define GPT_STAT_KD_TRIS (GPT_MAX_DEPTH + 1)
 #define GPT_STAT_HITS (GPT_MAX_DEPTH + 2)     // closest-hit queries that found something
-#define GPT_STAT_WORDS (GPT_MAX_DEPTH + 8)
+#define GPT_STAT_NODES_D0 (GPT_MAX_DEPTH + 8)          // [GPT_MAX_DEPTH] kd nodes visited per depth
+#define GPT_STAT_TRIS_D0 (2 * GPT_MAX_DEPTH + 8)       // [GPT_MAX_DEPTH] triangles tested per depth
+#define GPT_STAT_WORDS (3 * GPT_MAX_DEPTH + 8)
 
 struct DevGeometry {
     const float4* spheres;     // (centre.xyz, radius)

@@ -1,0 +1,105 @@
+// gpt_render -- headless renderer: what the reference's display.cpp main loop does
+// (display.cpp:69-110,183-259: build the camera, call PathTracer::render once per frame,
+// show floatTo8Bit(sum / passes)), without a window: the image goes to a PPM (and
+// optionally a PFM with raw radiance).  Pure caller of the C-ABI in include/gpt.h.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpt.h"
+
+static void usage() {
+    fprintf(stderr,
+            "usage: gpt_render [--width W] [--height H] [--spp N] [--depth D] [--out image.ppm] [--pfm image.pfm]\n"
+            "                  [--obj mesh.obj [--material NAME] [--scale S] [--translate X Y Z]] [--no-spheres]\n"
+            "                  [--yaw R] [--pitch R] [--radius R] [--aperture R] [--fovx DEG] [--center X Y Z]\n"
+            "                  [--brute-force] [--device N]\n");
+}
+
+int main(int argc, char** argv) {
+    int width = 512, height = 512, spp = 64, depth = 30, device = 0;   // display.cpp:33-34, MAX_TRACE_DEPTH
+    std::string out = "render.ppm", pfm, obj, material = "glass";
+    float scale = 1, tr[3] = {0, 0, 0};
+    float yaw = 0, pitch = 0.3f, radius = 4, aperture = 0.04f, fovx = 45, center[3] = {0, 0, 0};
+    bool spheres_on = true, brute = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { usage(); exit(2); } };
+        if (a == "--width") { need(1); width = atoi(argv[++i]); }
+        else if (a == "--height") { need(1); height = atoi(argv[++i]); }
+        else if (a == "--spp") { need(1); spp = atoi(argv[++i]); }
+        else if (a == "--depth") { need(1); depth = atoi(argv[++i]); }
+        else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); out = argv[++i]; }
+        else if (a == "--pfm") { need(1); pfm = argv[++i]; }
+        else if (a == "--obj") { need(1); obj = argv[++i]; }
+        else if (a == "--material") { need(1); material = argv[++i]; }
+        else if (a == "--scale") { need(1); scale = (float)atof(argv[++i]); }
+        else if (a == "--translate") { need(3); for (int k = 0; k < 3; k++) tr[k] = (float)atof(argv[++i]); }
+        else if (a == "--center") { need(3); for (int k = 0; k < 3; k++) center[k] = (float)atof(argv[++i]); }
+        else if (a == "--yaw") { need(1); yaw = (float)atof(argv[++i]); }
+        else if (a == "--pitch") { need(1); pitch = (float)atof(argv[++i]); }
+        else if (a == "--radius") { need(1); radius = (float)atof(argv[++i]); }
+        else if (a == "--aperture") { need(1); aperture = (float)atof(argv[++i]); }
+        else if (a == "--fovx") { need(1); fovx = (float)atof(argv[++i]); }
+        else if (a == "--no-spheres") spheres_on = false;
+        else if (a == "--brute-force") brute = true;
+        else { usage(); return 2; }
+    }
+    if (width <= 0 || height <= 0 || spp <= 0) { usage(); return 2; }
+
+    std::vector<Sphere> spheres;
+    if (spheres_on) { spheres.resize((size_t)gpt_default_scene_sphere_count()); gpt_default_scene(spheres.data()); }
+    Poly* polys = nullptr;
+    int numPolys = 0;
+    if (!obj.empty()) {
+        Material m;
+        if (gpt_material_preset(material.c_str(), &m) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+        float bbox[6];
+        if (gpt_obj_load(obj.c_str(), &m, &polys, &numPolys, bbox) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+        printf("Loaded %d faces from %s\n", numPolys, obj.c_str());
+        for (int i = 0; i < numPolys; i++) {
+            GPT_FLOAT3* v[3] = {&polys[i].p0, &polys[i].p1, &polys[i].p2};
+            for (int k = 0; k < 3; k++) {
+                v[k]->x = v[k]->x * scale + tr[0]; v[k]->y = v[k]->y * scale + tr[1]; v[k]->z = v[k]->z * scale + tr[2];
+            }
+        }
+    }
+    gpt_render_params rp;
+    gpt_render_params_default(&rp);
+    rp.max_depth = depth;
+    rp.use_kdtree = brute ? 0 : 1;
+    Camera cam;
+    gpt_orbit_camera((float)width, (float)height, fovx, yaw, pitch, radius, aperture, center, &cam);
+
+    gpt_scene* scene = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    if (gpt_scene_create(spheres.data(), (int)spheres.size(), polys, numPolys, &rp, device, &scene) != GPT_OK ||
+        gpt_scene_reset(scene, width * height) != GPT_OK) {
+        fprintf(stderr, "%s\n", gpt_last_error());
+        return 1;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (gpt_render_range(scene, &cam, 0, spp, 1) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+    auto t2 = std::chrono::steady_clock::now();
+    std::vector<float> img((size_t)width * height * 3);
+    int passes = 0;
+    gpt_stats st;
+    if (gpt_accum_download(scene, img.data(), &passes) != GPT_OK || gpt_get_stats(scene, &st) != GPT_OK) {
+        fprintf(stderr, "%s\n", gpt_last_error());
+        return 1;
+    }
+    double sec = std::chrono::duration<double>(t2 - t1).count();
+    // the reference's overlay: iterations, seconds, FPS (display.cpp:232-250)
+    printf("Iterations: %d\nSeconds: %.3f\nFPS: %.2f\n", passes, sec, passes / (sec > 0 ? sec : 1));
+    printf("Scene upload + kd-tree: %.3f s; %.1f Mpath-bounces/s\n", std::chrono::duration<double>(t1 - t0).count(),
+           (double)st.path_bounces / (sec > 0 ? sec : 1) / 1e6);
+    if (gpt_write_ppm(out.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+    if (!pfm.empty() && gpt_write_pfm(pfm.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+    gpt_scene_destroy(scene);
+    gpt_free(polys);
+    return 0;
+}

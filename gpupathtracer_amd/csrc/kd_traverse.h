@@ -32,6 +32,7 @@ struct TriRec { float f[12]; };
 struct KdView {
     const KdNode* nodes;
     const TriRec* leaf_tris;   // one record per (leaf, triangle) reference, leaf by leaf
+    const int32_t* refs;       // non-null: leaves index `leaf_tris` (then one record per triangle) through this list
     float bmin[3], bmax[3];
     float sigma;       // spatial slack: 2e-5 * largest extent of the root box
 };
@@ -155,7 +156,8 @@ struct KdCursor {
         const uint32_t first = w.w0 >> 2, count = w.w1;
         for (uint32_t k = 0; k < count; k++) {
             V3 a, e1, e2;
-            const int idx = load_tri(kd.leaf_tris, (size_t)first + k, a, e1, e2);
+            const size_t rec = kd.refs ? (size_t)kd.refs[first + k] : (size_t)first + k;
+            const int idx = load_tri(kd.leaf_tris, rec, a, e1, e2);
             float t;
             if (STATS) trisTested++;
             if (triangle_t(a, e1, e2, o, d, t)) {

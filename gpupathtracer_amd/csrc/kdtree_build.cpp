@@ -318,8 +318,8 @@ void treelet_layout(const Tree& in, std::vector<Node>& out) {
     std::vector<uint32_t> new_index(src.size(), 0u); // old node index -> new node index
     std::vector<std::pair<uint32_t, uint32_t>> placed;   // (old, new) in placement order
     while (!roots.empty()) {
-        // start a new line
-        while (out.size() % (2 * kPairsPerLine) != 0) out.push_back(pad);
+        // Pieces are laid back to back (no padding): a piece of up to 8 pairs spans at most
+        // two lines.  Only the first line is aligned (the root pair starts it).
         std::deque<Pair> frontier;
         frontier.push_back(roots.front());
         roots.pop_front();

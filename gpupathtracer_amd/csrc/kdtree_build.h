@@ -28,7 +28,7 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out);
 // Device storage order of the nodes: the same tree with its nodes renumbered so that
 // every 128-byte line (16 nodes = 8 sibling pairs) holds a connected piece of the tree
 // (a pair, its child pairs, their child pairs ... breadth-first until the line is
-// full), lines padded with unused leaf words where a piece is smaller.  A root-to-leaf
+// full); pieces are stored back to back, so each spans at most two lines.  A root-to-leaf
 // walk then touches a new line every ~3 levels instead of every level.  Sibling pairs
 // stay adjacent and start at even indices; the root stays node 0.  The triangle
 // references (refs) are untouched.

@@ -226,6 +226,8 @@ typedef struct gpt_stats {
     double   device_ms_trace;     /* HIP-event time of the intersect kernels   */
     double   device_ms_total;     /* HIP-event time of whole passes            */
     uint64_t trace_launches;
+    uint64_t kd_nodes_at_depth[64];   /* instrumented build only */
+    uint64_t kd_tris_at_depth[64];
 } gpt_stats;
 gpt_status gpt_get_stats(gpt_scene* scene, gpt_stats* out);
 

@@ -54,6 +54,7 @@ void* hh_tree_build(const float* verts, int n, int small_threshold, float traver
     for (size_t r = 0; r < h->tree.refs.size(); r++) h->leaf_tris[r] = h->tris[(size_t)h->tree.refs[r]];
     h->view.nodes = (const KdNode*)h->dev_nodes.data();
     h->view.leaf_tris = h->leaf_tris.data();
+    h->view.refs = nullptr;
     float ext = 0;
     for (int k = 0; k < 3; k++) {
         h->view.bmin[k] = h->tree.bounds[k]; h->view.bmax[k] = h->tree.bounds[3 + k];

@@ -1,0 +1,140 @@
+"""GPU: BASELINE-size configurations.  The oracle cannot render 2 M pixels x 1.5 M
+triangles in test time, so full-size runs are checked (a) against the oracle on strided
+pixel subsets (every pixel of a pass is independent of every other), (b) kd traversal
+against the device's own brute-force loop on the frame's primary rays, and (c) through
+size-independent properties: determinism, independence from the number of passes traced
+per launch, image = sum of passes, pass-count bookkeeping."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes as S
+from gpupathtracer_amd import api, meshes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def strided_ids(w, h, stride):
+    ys, xs = np.meshgrid(np.arange(stride // 2, h, stride), np.arange(stride // 2, w, stride), indexing="ij")
+    return (ys * w + xs).astype(np.int32).ravel()
+
+
+def test_spheres_1080p_against_oracle_subset():
+    """Config: the reference's default scene at 1920x1080 (width-stride fix), depth 8."""
+    w, h, depth = 1920, 1080, 8
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    ids = strided_ids(w, h, 13)
+    with api.Scene(sph, None, api.render_params(max_depth=depth)) as sc:
+        got = sc.render_pass(cam, 4)
+        again = sc.render_pass(cam, 4)
+        st = sc.stats()
+    assert np.array_equal(got, again)                       # deterministic
+    ref = O.render_pass(sph, None, cam, 4, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids)
+    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
+    assert (rel > 1e-4).mean() < 2e-3
+    assert st["live_at_depth"][0] == 2 * w * h
+    # bounces per path of the default scene at depth 8 (reference run: 2.69 at 512x512)
+    assert 2.4 < st["path_bounces"] / (2 * w * h) < 3.0
+
+
+def test_cow_heavy_1080p_kd_vs_brute_and_oracle():
+    """Config: cow subdivided 3x (371 456 triangles, glass) + default spheres, 1080p, depth 8."""
+    w, h, depth = 1920, 1080, 8
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    v, n = meshes.load_asset("cow")
+    v, n = meshes.subdivide(v, n, 3)
+    polys = meshes.polys_from_triangles(v, n, S.MATERIALS["glass"])
+    with api.Scene(sph, polys, api.render_params(max_depth=depth)) as sc:
+        prim, t = sc.primary_hits(cam, 0)
+        # primary rays of a strided subset: traversal vs the brute-force loop on the device, bit-exact
+        ids = strided_ids(w, h, 9)
+        rays = O.camera_rays(cam, 0, O.params(row_stride_is_width=1), pixel_ids=ids)
+        tk, ttk = sc.intersect(rays, use_kdtree=True)
+        tb, ttb = sc.intersect(rays, use_kdtree=False)
+        assert np.array_equal(tk, tb) and np.array_equal(ttk.view(np.int32), ttb.view(np.int32))
+        assert (tb >= 0).sum() > 500
+        got = sc.render_pass(cam, 0)
+        info = sc.info()
+    assert info["kd_depth"] <= 56 and info["kd_nodes"] > 1000
+    # first-hit triangle indices of primary rays against the oracle (brute force, pixel subset)
+    ids = strided_ids(w, h, 40)
+    ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids,
+                        want_hits=True)
+    assert (prim[ids] != ref["hits"]["prim"]).mean() < 2e-3          # lens sincos last-bit cases only
+    on_mesh = (ref["hits"]["prim"] >= 0) & (ref["hits"]["prim"] < polys.size)
+    assert on_mesh.sum() > 20
+    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
+    assert (rel > 1e-4).mean() < 1e-2
+
+
+def test_passes_per_launch_do_not_change_the_image():
+    w, h = 640, 360
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    v, n = meshes.load_asset("monkey")
+    v = meshes.transform(v, 0.5, (0.0, -0.2, 1.5))
+    polys = meshes.polys_from_triangles(v, n, S.MATERIALS["something"])
+    images = []
+    for batch in (1, 5, 16):
+        with api.Scene(sph, polys, api.render_params(max_depth=10, passes_in_flight=batch)) as sc:
+            sc.reset(w * h)
+            sc.render_range(cam, 3, 3 + 11)
+            img, passes = sc.accum_download()
+            st = sc.stats()
+            assert passes == 11 and st["passes"] == 11
+            images.append((img, st["path_bounces"], st["live_at_depth"].copy()))
+    for img, pb, live in images[1:]:
+        assert np.array_equal(img, images[0][0]) and pb == images[0][1] and np.array_equal(live, images[0][2])
+
+
+def test_converged_image_rmse_against_oracle():
+    """Image-level agreement: 64 spp of the box scene, RMSE of the mean image."""
+    w = h = 128
+    spp, depth = 64, 8
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    bv, bn = meshes.load_asset("box")
+    bv = meshes.transform(bv, 0.35, (0.0, -0.45, 1.9))
+    polys = meshes.polys_from_triangles(bv, bn, S.MATERIALS["glass"])
+    with api.Scene(sph, polys, api.render_params(max_depth=depth)) as sc:
+        sc.reset(w * h)
+        sc.render_range(cam, 0, spp)
+        img, passes = sc.accum_download()
+    assert passes == spp
+    ref = np.zeros((w * h, 3), np.float32)
+    p = O.params(max_depth=depth, row_stride_is_width=1)
+    for c in range(spp):
+        ref += O.render_pass(sph, polys, cam, c, p)["rgb"]
+    a, b = img / spp, ref / spp
+    rmse = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
+    # a branch flip changes one sample of one pixel by O(1); at 64 spp and <0.2 % flipped samples the
+    # mean image moves by far less than the Monte-Carlo noise (~0.05).  Bound: 2e-3.
+    assert rmse < 2e-3, rmse
+    assert np.array_equal(api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp), np.zeros((w * h, 3), bool)) or \
+        (api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp)).mean() < 5e-3
+
+
+def test_headless_renderer_cli(tmp_path):
+    exe = os.path.join(ROOT, "gpupathtracer_amd", "lib", "gpt_render")
+    assert os.path.exists(exe), "gpt_render has not been built (make -C gpupathtracer_amd/csrc)"
+    ppm = str(tmp_path / "o.ppm")
+    pfm = str(tmp_path / "o.pfm")
+    out = subprocess.run([exe, "--width", "96", "--height", "64", "--spp", "6", "--depth", "8", "--out", ppm,
+                          "--pfm", pfm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Iterations: 6" in out.stdout
+    cam = api.orbit_camera(96, 64)
+    with api.Scene(api.default_scene(), None, api.render_params(max_depth=8)) as sc:
+        sc.reset(96 * 64)
+        sc.render_range(cam, 0, 6)
+        img, passes = sc.accum_download()
+    raw = open(ppm, "rb").read()
+    header = b"P6\n96 64\n255\n"
+    assert raw.startswith(header)
+    assert raw[len(header):] == api.tonemap_8bit(img, 6).tobytes()

@@ -1,0 +1,50 @@
+"""Copies the judged summaries of a tools/gpu_profile.sh run into profiles/ :
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+  profiles/<tag>_pmc_summary.json   per-kernel sums of the PMC passes + derived figures
+  profiles/traffic.json             HBM-side bytes per k_intersect_kd launch (read by bench.py)
+Usage: collect_profiles.py gpurun_out/prof_<tag> <tag>"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parse_prof  # noqa: E402
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(out, tag + "_kernel_stats.csv"))
+summary = os.path.join(out, tag + "_pmc_summary.json")
+parse_prof.main(src, summary)
+d = json.load(open(summary))
+key = [k for k in d["counters"] if "k_intersect_kd<false>" in k][0]
+c = d["counters"][key]
+n = c["_dispatches"]["pmc_rdreq"]
+read_bytes = 32 * c["TCC_EA0_RDREQ_32B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c["TCC_EA0_RDREQ_128B_sum"]
+write_bytes = c["WRITE_SIZE"] * 1024
+derived = {
+    "kernel": key,
+    "dispatches": n,
+    "read_bytes_per_launch": read_bytes / n,
+    "write_bytes_per_launch": write_bytes / c["_dispatches"]["pmc_write"],
+    "fetch_size_kb_per_launch": c["FETCH_SIZE"] / c["_dispatches"]["pmc_fetch"],
+    "fetch_size_x2_bytes_per_launch": 2 * 1024 * c["FETCH_SIZE"] / c["_dispatches"]["pmc_fetch"],
+    "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+    "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+    "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+    "wave_cycles_issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+    "avg_launch_us_traced": d["kernels"][key]["avg_us"],
+}
+d["derived_k_intersect_kd"] = derived
+json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
+json.dump({
+    "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
+    "how": "rocprofv3 --pmc, separate passes: sum(TCC_EA0_RDREQ_{32,64,128}B_sum x request size) + WRITE_SIZE*1024, "
+           "divided by the kernel's dispatches; bench.py --steps 32 --warmup 0 --batch 32 (8 launches of 32 passes)",
+    "source": tag + "_pmc_summary.json",
+}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print(json.dumps(derived, indent=1))
