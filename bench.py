@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
+TRIS = [10000000]
 
 
 def build_workload(name, subdiv):
@@ -47,12 +48,23 @@ def build_workload(name, subdiv):
         polys = meshes.polys_from_triangles(v, n, api.material_preset("glass"))
     elif name == "spheres":
         polys = None
+    elif name == "diamond_coil":
+        # glass diamond + marble (subsurface) coil moved into view, lens on: long refractive / medium tails
+        dv, dn = meshes.load_asset("diamond")
+        cv, cn = meshes.load_asset("coil")
+        polys = np.concatenate([
+            meshes.polys_from_triangles(meshes.transform(dv, 0.8, (0.2, -2.2, 2.6)), dn, api.material_preset("glass")),
+            meshes.polys_from_triangles(meshes.transform(cv, 0.25, (-1.2, -2.2, 1.2)), cn, api.material_preset("marble"))])
+    elif name == "soup":
+        # synthetic mesh: 10 M (or --tris) small triangles uniformly in [-1,1]^3, lifted above the ground
+        v, n = meshes.random_soup(TRIS[0], seed=12345, extent=1.0, edge=0.01)
+        polys = meshes.polys_from_triangles(meshes.transform(v, 0.75, (0.0, 0.1, 0.0)), n, api.material_preset("white"))
     else:
         raise SystemExit("unknown workload " + name)
     return spheres, polys
 
 
-def cpu_baseline(spheres, polys, cam, depth, target_seconds=20.0):
+def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
     """The oracle (reference algorithm, brute-force triangle loop) on a strided pixel subset."""
     import oracle_lib as O
     w, h = int(cam["resolution"][0]), int(cam["resolution"][1])
@@ -87,14 +99,15 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cow_heavy")
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=32, help="passes traced together per launch")
+    ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
+    ap.add_argument("--batch", type=int, default=128, help="passes traced together per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
@@ -111,11 +124,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # GPT_FORCE_DIST=1 exercises the RCCL path with a single rank (one-GPU boxes)
+    distributed = world > 1 or os.environ.get("GPT_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    TRIS[0] = args.tris
     spheres, polys = build_workload(args.workload, args.subdiv)
     cam = api.default_camera(args.width, args.height)
     n_pix = args.width * args.height
@@ -200,10 +215,13 @@ def main():
             "data": "synthetic",
             "spp_per_s": world * K / elapsed_max,
             "config": {
-                "workload": "%s: cow.obj subdivided %dx (%d triangles, glass) + the reference's 14 spheres, "
+                "workload": "%s: %s (%d triangles) + the reference's 14 spheres, "
                             "ground and sky; default orbit camera %dx%d, depth %d, 1 spp per step, kd-tree"
-                            % (args.workload, args.subdiv, 0 if polys is None else polys.size,
-                               args.width, args.height, args.depth),
+                            % (args.workload,
+                               {"cow_heavy": "cow.obj subdivided %dx, glass" % args.subdiv,
+                                "spheres": "no mesh", "diamond_coil": "glass diamond + marble coil",
+                                "soup": "uniform random small white triangles"}[args.workload],
+                               0 if polys is None else polys.size, args.width, args.height, args.depth),
                 "passes_per_gpu": K,
                 "passes_per_launch": args.batch,
                 "parallelism": "spp-sharded x%d, one RCCL sum-reduce of the float4 image" % world,
@@ -211,7 +229,7 @@ def main():
                 "kd": dict(scene.info(), build_and_upload_s=round(t_build, 2)),
             },
             "roofline": {
-                "kernel": "k_intersect<kd>",
+                "kernel": "k_intersect_kd<false>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -24,6 +24,10 @@ class GptStats(ctypes.Structure):
         ("trace_launches", ctypes.c_uint64),
         ("kd_nodes_at_depth", ctypes.c_uint64 * 64),
         ("kd_tris_at_depth", ctypes.c_uint64 * 64),
+        ("wave_iters_node", ctypes.c_uint64),
+        ("wave_iters_tri", ctypes.c_uint64),
+        ("busy_lane_rounds", ctypes.c_uint64),
+        ("wave_rounds", ctypes.c_uint64),
     ]
 
 

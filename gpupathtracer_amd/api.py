@@ -136,6 +136,10 @@ class Scene:
             "trace_launches": int(st.trace_launches),
             "kd_nodes_at_depth": np.array(st.kd_nodes_at_depth[:], dtype=np.int64),
             "kd_tris_at_depth": np.array(st.kd_tris_at_depth[:], dtype=np.int64),
+            "wave_iters_node": int(st.wave_iters_node),
+            "wave_iters_tri": int(st.wave_iters_tri),
+            "busy_lane_rounds": int(st.busy_lane_rounds),
+            "wave_rounds": int(st.wave_rounds),
         }
 
     def info(self):

@@ -38,6 +38,7 @@ void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const fl
 void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
                           int32_t* tri, float* t_out, uint32_t* spill, size_t spill_stride);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
+void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
 }
 
 namespace {
@@ -250,6 +251,7 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
                    s->d_hit, s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
     }
     gptk_finish(s->stream, pixel_grid(N), N, P, s->d_pass, s->d_image, pass3);
+    if (s->kd_stats) gptk_collect_wave_iters(s->stream, s->d_stats);
     HIP_TRY(hipGetLastError());
     if (s->profile) {
         gpt_status st = get_event(s, &e1); if (st) return st;
@@ -303,7 +305,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
     if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 64;
     if (rp.passes_in_flight <= 0) rp.passes_in_flight = 1;
-    if (rp.passes_in_flight > 64) rp.passes_in_flight = 64;
+    if (rp.passes_in_flight > 512) rp.passes_in_flight = 512;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -361,6 +363,9 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         std::vector<gptkd::Node> dev_nodes;
         gptkd::treelet_layout(tree, dev_nodes);
         s->n_nodes = (int)dev_nodes.size();
+        std::vector<int32_t> dev_refs;
+        if (getenv("GPT_NO_DFS_LEAVES")) dev_refs = tree.refs;
+        else gptkd::leaf_order_refs(dev_nodes, tree.refs, dev_refs);
         // Leaf triangles: records duplicated in leaf order while that copy stays well inside the
         // 256 MiB Infinity Cache together with the rest of the scene; otherwise an index list
         // into the per-triangle records (smaller footprint, one more dependent load).
@@ -368,8 +373,8 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if (const char* e = getenv("GPT_LEAF_ORDER")) leaf_order = atoi(e) != 0;
         std::vector<TriRec> leaf_recs;
         if (leaf_order) {
-            leaf_recs.resize(tree.refs.size());
-            for (size_t r = 0; r < tree.refs.size(); r++) leaf_recs[r] = recs[(size_t)tree.refs[r]];
+            leaf_recs.resize(dev_refs.size());
+            for (size_t r = 0; r < dev_refs.size(); r++) leaf_recs[r] = recs[(size_t)dev_refs[r]];
         }
 
         if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
@@ -381,7 +386,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if (leaf_order) {
             if ((st = upload(&s->d_leaf_tris, leaf_recs.data(), leaf_recs.size() * sizeof(TriRec)))) break;
         } else {
-            if ((st = upload(&s->d_refs, tree.refs.data(), tree.refs.size() * 4))) break;
+            if ((st = upload(&s->d_refs, dev_refs.data(), dev_refs.size() * 4))) break;
         }
 
         s->spill_stride = (size_t)kTraceGrid * kBlock;
@@ -572,6 +577,10 @@ gpt_status gpt_get_stats(gpt_scene* s, gpt_stats* out) {
     out->kd_nodes_visited = h[GPT_STAT_KD_NODES];
     out->kd_tris_tested = h[GPT_STAT_KD_TRIS];
     out->hits = h[GPT_STAT_HITS];
+    out->wave_iters_node = h[GPT_STAT_WAVE_ITERS_NODE];
+    out->wave_iters_tri = h[GPT_STAT_WAVE_ITERS_TRI];
+    out->busy_lane_rounds = h[GPT_STAT_BUSY_LANE_ROUNDS];
+    out->wave_rounds = h[GPT_STAT_WAVE_ROUNDS];
     for (int d = 0; d < GPT_MAX_DEPTH; d++) {
         out->kd_nodes_at_depth[d] = h[GPT_STAT_NODES_D0 + d];
         out->kd_tris_at_depth[d] = h[GPT_STAT_TRIS_D0 + d];

@@ -23,6 +23,16 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// wave-iteration counters of the instrumented traversal (first active lane counts)
+__device__ unsigned long long g_wave_iters[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_COUNT_WAVE_ITERATION(slot)                                                          \
+    do {                                                                                       \
+        const unsigned long long m_ = __ballot(1);                                             \
+        if (__builtin_amdgcn_mbcnt_hi((unsigned)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_, 0u)) == 0u) \
+            atomicAdd(&g_wave_iters[slot], 1ull);                                              \
+    } while (0)
+#endif
 #include "gpt_device_structs.h"
 #include "kd_traverse.h"
 #include "pt_device.h"
@@ -167,7 +177,7 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
 
 // ---------------------------------------------------------------------------
 // k_intersect_brute: closest hit with the reference's loop over every triangle
-// (:536-557).  Waves pull 64 queue slots at a time from a global work counter.
+// (:536-557); also the closest-hit kernel of scenes without triangles.
 // ---------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, int depth,
@@ -180,12 +190,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
     const unsigned n = counts[depth];
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
     uint32_t cTris = 0, cHits = 0;
-    const unsigned lane = lane_id();
-    for (;;) {
-        const unsigned base = wave_fetch(&work[depth], 64u);
-        if (base >= n) break;
-        const unsigned i = base + lane;
-        if (i < n) {
+    // every ray costs the same here, so the queue is split statically (no work counter)
+    const unsigned stride = gridDim.x * GPT_BLOCK;
+    for (unsigned i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < n; i += stride) {
+        {
             const float4 ro = ray_o[i];
             const float4 rd = ray_d[i];
             const V3 o = v3(ro.x, ro.y, ro.z);
@@ -221,7 +229,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
 //             root box) or start a traversal;
 //   traverse: lanes advance leaf by leaf (KdCursor::advance) until fewer than
 //             `refill_below` lanes are still busy, then the wave goes back to refill.
-//             (A one-node-or-one-triangle-per-iteration variant measured 5 % slower.)
+//             (Variants that bound the work per lane per round -- one node or one
+//             triangle, or up to 3..12 nodes + 1..4 triangles -- raise SIMD utilisation
+//             of the loops but measured within +-5 % of this one: the kernel is bound
+//             by L1 miss handling, not by VALU issue.)
 // Once the queue is drained the remaining lanes simply run to completion.
 // ---------------------------------------------------------------------------
 template <bool STATS>
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     cur.st.spill_stride = spill_stride;
     cur.st.reset();
 
-    uint32_t cNodes = 0, cTris = 0, cHits = 0;
+    uint32_t cNodes = 0, cTris = 0, cHits = 0, cBusy = 0, cRounds = 0;
     bool have = false;          // this lane holds an unfinished traversal
     bool drained = false;       // wave-uniform: the work queue is exhausted
     unsigned slot = 0;          // queue slot of the ray this lane is tracing
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
         }
         // ---- traverse ----
         while (have) {
+            if (STATS) { cBusy++; if (prefix_count(__ballot(1)) == 0u) cRounds++; }
             if (cur.advance(g.kd, cNodes, cTris)) {
                 const int prim = cur.bestTri >= 0 ? cur.bestTri : prim0;
                 hit[slot] = make_float2(cur.bestT, __int_as_float(prim));
@@ -310,6 +322,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
         atomicAdd(&stats[GPT_STAT_KD_TRIS], (unsigned long long)cTris);
         atomicAdd(&stats[GPT_STAT_HITS], (unsigned long long)cHits);
         atomicAdd(&stats[GPT_STAT_NODES_D0 + depth], (unsigned long long)cNodes);
+        atomicAdd(&stats[GPT_STAT_BUSY_LANE_ROUNDS], (unsigned long long)cBusy);
+        atomicAdd(&stats[GPT_STAT_WAVE_ROUNDS], (unsigned long long)cRounds);
         atomicAdd(&stats[GPT_STAT_TRIS_D0 + depth], (unsigned long long)cTris);
     }
 }
@@ -519,6 +533,13 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_debug_intersect(DevGeometry g, co
     }
 }
 
+__global__ void k_collect_wave_iters(unsigned long long* stats) {
+    if (threadIdx.x < 2) {
+        stats[GPT_STAT_WAVE_ITERS_NODE + threadIdx.x] += g_wave_iters[threadIdx.x];
+        g_wave_iters[threadIdx.x] = 0;
+    }
+}
+
 // Order-independent checksum of a device buffer (launchKernel's scene cache key).
 __global__ __launch_bounds__(GPT_BLOCK) void k_checksum(const uint32_t* __restrict__ words, size_t n,
                                                         unsigned long long* __restrict__ out) {
@@ -585,6 +606,10 @@ void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use
     else
         hipLaunchKernelGGL((k_debug_intersect<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, rays, n, tri, t_out,
                            spill, spill_stride);
+}
+
+void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {
+    hipLaunchKernelGGL(k_collect_wave_iters, dim3(1), dim3(64), 0, s, stats);
 }
 
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out) {

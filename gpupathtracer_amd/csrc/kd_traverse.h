@@ -39,6 +39,13 @@ struct KdView {
 
 #define PT_KD_REL_SLACK 4e-6f
 
+// Instrumented builds only: counts how many times a WAVE executes the body of the node loop
+// (slot 0) and of the triangle loop (slot 1), to relate them to the lanes' own counts
+// (SIMD utilisation of each loop).  The kernels define the macro; elsewhere it is empty.
+#ifndef PT_COUNT_WAVE_ITERATION
+#define PT_COUNT_WAVE_ITERATION(slot) ((void)0)
+#endif
+
 PT_HD float sel3(int axis, float x, float y, float z) { return axis == 0 ? x : (axis == 1 ? y : z); }
 
 PT_HD float bits_to_float(uint32_t u) {
@@ -84,6 +91,9 @@ struct KdCursor {
     // false: the ray cannot hit any triangle (it misses the padded root box).
     PT_HD bool begin(const KdView& kd, V3 o_, V3 d_, float t_limit) {
         o = o_; d = d_;
+        // a ray with a NaN component hits nothing in the reference's loop (every comparison of
+        // its triangle test fails); it must not wander through the tree either
+        if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return false;
         bestT = t_limit;
         bestTri = -1;
         tmin = 0.0f;
@@ -112,11 +122,21 @@ struct KdCursor {
         return true;
     }
 
+    // Next deferred interval that can still hold a closer (or equal) hit; false: none left.
+    PT_HD bool next_interval() {
+        do {
+            if (!st.pop(node, tmin, tmax)) return false;
+        } while (bestT < tmin);
+        tmax = fminf(tmax, bestT);
+        return true;
+    }
+
     // One leaf visit.  Returns true when the traversal is complete.
     PT_HD bool advance(const KdView& kd, uint32_t& nodesVisited, uint32_t& trisTested) {
         KdNode w = kd.nodes[node];
         if (STATS) nodesVisited++;
         while ((w.w0 & 3u) != 3u) {
+            if (STATS) PT_COUNT_WAVE_ITERATION(0);
             const int axis = (int)(w.w0 & 3u);
             const float split = bits_to_float(w.w1);
             const uint32_t left = w.w0 >> 2;
@@ -126,35 +146,33 @@ struct KdCursor {
             const bool leftFirst = (oa < split) || (oa == split && da <= 0.0f);
             const uint32_t nearC = leftFirst ? left : left + 1u;
             const uint32_t farC = leftFirst ? left + 1u : left;
-            if (da == 0.0f) {
-                // parallel to the plane: one side, or both when inside the slab
-                if (fabsf(oa - split) <= kd.sigma) st.push(farC, tmin, tmax);
-                node = nearC;
-            } else {
-                const float tp = (split - oa) * ia;
-                const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
-                const float lo = tp - s, hi = tp + s;
-                if (lo > tmax || hi < 0.0f) {
-                    node = nearC;                 // plane beyond the interval or behind the origin
-                } else if (lo < 0.0f) {
-                    // origin inside the thickened plane: the crossing may be real or lie
-                    // behind the origin, so either side can own the whole interval
-                    st.push(farC, tmin, tmax);
-                    node = nearC;
-                } else if (hi < tmin) {
-                    node = farC;                  // plane crossed before the interval starts
-                } else {
-                    st.push(farC, fmaxf(tmin, lo), tmax);
-                    node = nearC;
-                    tmax = fminf(tmax, hi);
-                }
-            }
+            // The four outcomes are computed with selects (the lanes of a wave rarely agree on
+            // the outcome, and separate branches would run one after the other):
+            //   near only   plane beyond the interval, or behind the origin, or ray parallel
+            //               to it and outside the thickened plane
+            //   both, whole interval each   origin inside the thickened plane (the crossing may
+            //               be real or lie behind the origin), or parallel inside it
+            //   far only    plane crossed before the interval starts
+            //   both, cut   near gets [tmin, min(tmax,hi)], far gets [max(tmin,lo), tmax]
+            const bool parallel = (da == 0.0f);
+            const bool inSlab = fabsf(oa - split) <= kd.sigma;
+            const float tp = (split - oa) * ia;
+            const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
+            const float lo = tp - s, hi = tp + s;
+            const bool nearOnly = parallel ? !inSlab : (lo > tmax || hi < 0.0f);
+            const bool bothWhole = parallel ? inSlab : (!nearOnly && lo < 0.0f);
+            const bool farOnly = !parallel && !nearOnly && !bothWhole && hi < tmin;
+            const bool bothCut = !parallel && !nearOnly && !bothWhole && !farOnly;
+            if (bothWhole || bothCut) st.push(farC, bothCut ? fmaxf(tmin, lo) : tmin, tmax);
+            node = farOnly ? farC : nearC;
+            tmax = bothCut ? fminf(tmax, hi) : tmax;
             w = kd.nodes[node];
             if (STATS) nodesVisited++;
         }
         // ---- leaf ----
         const uint32_t first = w.w0 >> 2, count = w.w1;
         for (uint32_t k = 0; k < count; k++) {
+            if (STATS) PT_COUNT_WAVE_ITERATION(1);
             V3 a, e1, e2;
             const size_t rec = kd.refs ? (size_t)kd.refs[first + k] : (size_t)first + k;
             const int idx = load_tri(kd.leaf_tris, rec, a, e1, e2);
@@ -167,12 +185,7 @@ struct KdCursor {
                 }
             }
         }
-        // ---- next deferred interval that can still hold a closer (or equal) hit ----
-        do {
-            if (!st.pop(node, tmin, tmax)) return true;
-        } while (bestT < tmin);
-        tmax = fminf(tmax, bestT);
-        return false;
+        return !next_interval();
     }
 };
 

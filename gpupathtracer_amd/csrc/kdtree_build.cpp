@@ -321,8 +321,8 @@ void treelet_layout(const Tree& in, std::vector<Node>& out) {
         // Pieces are laid back to back (no padding): a piece of up to 8 pairs spans at most
         // two lines.  Only the first line is aligned (the root pair starts it).
         std::deque<Pair> frontier;
-        frontier.push_back(roots.front());
-        roots.pop_front();
+        frontier.push_back(roots.back());              // depth-first over pieces: a subtree's pieces
+        roots.pop_back();                              // end up next to each other in memory
         uint32_t used = 0;
         while (!frontier.empty() && used < kPairsPerLine) {
             Pair p = frontier.front();
@@ -338,7 +338,7 @@ void treelet_layout(const Tree& in, std::vector<Node>& out) {
             }
             used++;
         }
-        for (const Pair& p : frontier) roots.push_back(p);   // did not fit: new treelets
+        for (auto it = frontier.rbegin(); it != frontier.rend(); ++it) roots.push_back(*it);   // new pieces
     }
     // rewrite child links
     for (const auto& pn : placed) {
@@ -346,6 +346,31 @@ void treelet_layout(const Tree& in, std::vector<Node>& out) {
         if ((n.w0 & 3u) != 3u) {
             const uint32_t old_left = n.w0 >> 2;
             n.w0 = (new_index[old_left] << 2) | (n.w0 & 3u);
+        }
+    }
+}
+
+// Leaf-ordered copy of the triangle references: leaves visited left to right (depth first),
+// so leaves that are neighbours in space are neighbours in memory.  Rewrites the leaves'
+// first-reference fields of `nodes` (any node order) to point into `out_refs`.
+void leaf_order_refs(std::vector<Node>& nodes, const std::vector<int32_t>& refs, std::vector<int32_t>& out_refs) {
+    out_refs.clear();
+    out_refs.reserve(refs.size());
+    std::vector<uint32_t> stack;
+    stack.push_back(0u);
+    while (!stack.empty()) {
+        const uint32_t n = stack.back();
+        stack.pop_back();
+        Node& w = nodes[n];
+        if ((w.w0 & 3u) == 3u) {
+            const uint32_t first = w.w0 >> 2, count = w.w1;
+            const uint32_t at = (uint32_t)out_refs.size();
+            for (uint32_t k = 0; k < count; k++) out_refs.push_back(refs[first + k]);
+            w.w0 = (at << 2) | 3u;
+        } else {
+            const uint32_t left = w.w0 >> 2;
+            stack.push_back(left + 1u);
+            stack.push_back(left);
         }
     }
 }

@@ -34,4 +34,8 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out);
 // references (refs) are untouched.
 void treelet_layout(const Tree& in, std::vector<Node>& out_nodes);
 
+// Device storage order of the triangle references: depth-first (left to right) over the
+// leaves; `nodes` (in any order) get their leaves' first-reference fields rewritten.
+void leaf_order_refs(std::vector<Node>& nodes, const std::vector<int32_t>& refs, std::vector<int32_t>& out_refs);
+
 }  // namespace gptkd

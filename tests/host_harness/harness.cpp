@@ -50,8 +50,10 @@ void* hh_tree_build(const float* verts, int n, int small_threshold, float traver
     gptkd::build(verts, n, bp, h->tree);
     make_recs(verts, n, h->tris);
     gptkd::treelet_layout(h->tree, h->dev_nodes);
-    h->leaf_tris.resize(h->tree.refs.size());
-    for (size_t r = 0; r < h->tree.refs.size(); r++) h->leaf_tris[r] = h->tris[(size_t)h->tree.refs[r]];
+    std::vector<int32_t> dev_refs;
+    gptkd::leaf_order_refs(h->dev_nodes, h->tree.refs, dev_refs);
+    h->leaf_tris.resize(dev_refs.size());
+    for (size_t r = 0; r < dev_refs.size(); r++) h->leaf_tris[r] = h->tris[(size_t)dev_refs[r]];
     h->view.nodes = (const KdNode*)h->dev_nodes.data();
     h->view.leaf_tris = h->leaf_tris.data();
     h->view.refs = nullptr;

@@ -138,3 +138,33 @@ def test_headless_renderer_cli(tmp_path):
     header = b"P6\n96 64\n255\n"
     assert raw.startswith(header)
     assert raw[len(header):] == api.tonemap_8bit(img, 6).tobytes()
+
+
+def test_synthetic_soup_4k():
+    """Config: synthetic triangle soup (2 M here; the bench workload uses 10 M) at 3840x2160."""
+    w, h, depth = 3840, 2160, 8
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    v, n = meshes.random_soup(2000000, seed=12345, extent=1.0, edge=0.01)
+    v = meshes.transform(v, 0.75, (0.0, 0.1, 0.0))
+    polys = meshes.polys_from_triangles(v, n, S.MATERIALS["white"])
+    with api.Scene(sph, polys, api.render_params(max_depth=depth, passes_in_flight=2)) as sc:
+        ids = strided_ids(w, h, 24)
+        rays = O.camera_rays(cam, 1, O.params(row_stride_is_width=1), pixel_ids=ids)
+        tk, ttk = sc.intersect(rays, use_kdtree=True)
+        to, tto = O.closest_triangle(v, rays[:1500])
+        assert np.array_equal(tk[:1500], to) and np.array_equal(ttk[:1500].view(np.int32), tto.view(np.int32))
+        assert (tk >= 0).sum() > 1000
+        sc.reset(w * h)
+        sc.render_range(cam, 0, 2)
+        img, passes = sc.accum_download()
+        st = sc.stats()
+    assert passes == 2 and st["live_at_depth"][0] == 2 * w * h
+    assert np.isfinite(img).all() and img.min() >= 0 and 0.05 < img.mean() / 2 < 1.0
+    # one pass of a pixel subset against the oracle
+    ids = strided_ids(w, h, 90)
+    with api.Scene(sph, polys, api.render_params(max_depth=depth, passes_in_flight=1)) as sc:
+        got = sc.render_pass(cam, 0)
+    ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids)
+    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
+    assert (rel > 1e-4).mean() < 1e-2

@@ -18,6 +18,9 @@ print("info", sc.info())
 for d in range(8):
     live = st["live_at_depth"][d]
     print("depth %d live %9d nodes/path %6.1f tris/path %6.1f" % (d, live, st["kd_nodes_at_depth"][d] / max(1, live), st["kd_tris_at_depth"][d] / max(1, live)))
+print("node loop: lane visits %d, wave iterations %d -> lanes/iteration %.1f of 64" % (st["kd_nodes_visited"], st["wave_iters_node"], st["kd_nodes_visited"] / max(1, st["wave_iters_node"])))
+print("tri loop: lane tests %d, wave iterations %d -> lanes/iteration %.1f of 64" % (st["kd_tris_tested"], st["wave_iters_tri"], st["kd_tris_tested"] / max(1, st["wave_iters_tri"])))
+print("advance rounds: lane-level %d, wave-level %d -> busy lanes per round %.1f" % (st["busy_lane_rounds"], st["wave_rounds"], st["busy_lane_rounds"] / max(1, st["wave_rounds"])))
 sc.set_profiling(True, False)
 sc.reset(1920 * 1080)
 for rep in range(2):
