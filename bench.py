@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
     ap.add_argument("--batch", type=int, default=128, help="passes traced together per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
 
@@ -132,6 +133,8 @@ def main():
 
     TRIS[0] = args.tris
     spheres, polys = build_workload(args.workload, args.subdiv)
+    if args.no_spheres:
+        spheres = spheres[:0]
     cam = api.default_camera(args.width, args.height)
     n_pix = args.width * args.height
     K, W = args.steps, args.warmup

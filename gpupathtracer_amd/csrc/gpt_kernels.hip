@@ -42,6 +42,30 @@ using namespace pt;
 #define GPT_BLOCK 256
 
 // ---------------------------------------------------------------------------
+// Streaming accesses: the path queues are written once and read once per depth, GBs per
+// launch.  Marking them non-temporal keeps them from displacing the kd-tree and triangle
+// records in L2 / Infinity Cache, which every ray re-reads.
+// ---------------------------------------------------------------------------
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+    nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ld_stream(const float2* p) {
+    nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+    nt_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f4*>(p));
+}
+__device__ __forceinline__ void st_stream(float2* p, float2 v) {
+    nt_f2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f2*>(p));
+}
+
+// ---------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_id() {
@@ -95,10 +119,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels,
         const unsigned pass = i - (unsigned)pixel * (unsigned)numPasses;
         V3 o, d;
         camera_ray(cam, pixel, seed0 + pass, o, d);
-        ray_o[i] = make_float4(o.x, o.y, o.z, __int_as_float(pixel));
-        ray_d[i] = make_float4(d.x, d.y, d.z, __int_as_float(-1));   // medium: air
-        thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pass));
-        pass_rgb[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        st_stream(&ray_o[i], make_float4(o.x, o.y, o.z, __int_as_float(pixel)));
+        st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
+        st_stream(&thr[i], make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pass)));
+        st_stream(&pass_rgb[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = total;
 }
@@ -194,8 +218,8 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
     const unsigned stride = gridDim.x * GPT_BLOCK;
     for (unsigned i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < n; i += stride) {
         {
-            const float4 ro = ray_o[i];
-            const float4 rd = ray_d[i];
+            const float4 ro = ld_stream(&ray_o[i]);
+            const float4 rd = ld_stream(&ray_d[i]);
             const V3 o = v3(ro.x, ro.y, ro.z);
             const V3 d = v3(rd.x, rd.y, rd.z);
             float bestT;
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
                 brute_closest_hit<STATS>(g.tris, g.n_tris, o, d, bt, bi, cTris);
                 if (bi >= 0) { bestT = bt; prim = bi; }
             }
-            hit[i] = make_float2(bestT, __int_as_float(prim));
+            st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
             if (STATS && prim != PT_PRIM_MISS) cHits++;
         }
     }
@@ -282,8 +306,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned r = prefix_count(idle);
                 if (r < take) {
                     const unsigned i = local_next + r;
-                    const float4 ro = ray_o[i];
-                    const float4 rd = ray_d[i];
+                    const float4 ro = ld_stream(&ray_o[i]);
+                    const float4 rd = ld_stream(&ray_d[i]);
                     const V3 o = v3(ro.x, ro.y, ro.z);
                     const V3 d = v3(rd.x, rd.y, rd.z);
                     float bestT;
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                         slot = i;
                         prim0 = prim;
                     } else {
-                        hit[i] = make_float2(bestT, __int_as_float(prim));
+                        st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
                         if (STATS && prim != PT_PRIM_MISS) cHits++;
                     }
                 }
@@ -310,7 +334,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             if (STATS) { cBusy++; if (prefix_count(__ballot(1)) == 0u) cRounds++; }
             if (cur.advance(g.kd, cNodes, cTris)) {
                 const int prim = cur.bestTri >= 0 ? cur.bestTri : prim0;
-                hit[slot] = make_float2(cur.bestT, __int_as_float(prim));
+                st_stream(&hit[slot], make_float2(cur.bestT, __int_as_float(prim)));
                 if (STATS && prim != PT_PRIM_MISS) cHits++;
                 have = false;
             }
@@ -370,10 +394,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
         int pixel = 0, medium = -1;
         unsigned pass = 0;
         if (i < n) {
-            const float4 ro = in_o[i];
-            const float4 rd = in_d[i];
-            const float4 th = in_thr[i];
-            const float2 h = hit[i];
+            const float4 ro = ld_stream(&in_o[i]);
+            const float4 rd = ld_stream(&in_d[i]);
+            const float4 th = ld_stream(&in_thr[i]);
+            const float2 h = ld_stream(&hit[i]);
             o = v3(ro.x, ro.y, ro.z);
             d = v3(rd.x, rd.y, rd.z);
             thr = v3(th.x, th.y, th.z);
@@ -443,9 +467,9 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
             const unsigned base = s_base;
 #pragma unroll
             for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += GPT_BLOCK) {
-                out_o[base + k] = s_o[k];
-                out_d[base + k] = s_d[k];
-                out_thr[base + k] = s_t[k];
+                st_stream(&out_o[base + k], s_o[k]);
+                st_stream(&out_d[base + k], s_d[k]);
+                st_stream(&out_thr[base + k], s_t[k]);
             }
             // move the remainder (< 256 entries) to the front
             const unsigned rem = staged - SHADE_FLUSH;
@@ -471,9 +495,9 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
         __syncthreads();
         const unsigned base = s_base;
         for (unsigned k = threadIdx.x; k < staged; k += GPT_BLOCK) {
-            out_o[base + k] = s_o[k];
-            out_d[base + k] = s_d[k];
-            out_thr[base + k] = s_t[k];
+            st_stream(&out_o[base + k], s_o[k]);
+            st_stream(&out_d[base + k], s_d[k]);
+            st_stream(&out_thr[base + k], s_t[k]);
         }
     }
 }
