@@ -25,14 +25,17 @@ using pt::TriRec;
 
 // kernels (gpt_kernels.hip)
 extern "C" {
-void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, int numPasses, uint32_t seed0,
-                 float4* ray_o, float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts);
+void gptk_camera(hipStream_t s, int grid, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses,
+                 uint32_t seed0, float4* ray_o, float4* ray_d, float4* thr, float2* hit, float4* pass_rgb,
+                 unsigned* counts);
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
-                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below);
+                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
+                    unsigned leaf_min);
 void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
                 int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
-                float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work);
+                float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
+                unsigned long long* stats);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
 void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
@@ -133,10 +136,11 @@ struct gpt_scene {
     int numPixels = 0;
     int batch = 1;                           // passes traced together per launch
     unsigned refill_below = 48;              // k_intersect_kd: refill a wave when fewer lanes are busy
+    unsigned leaf_min = 24;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};
-    float2* d_hit = nullptr;
+    float2* d_hit[2] = {nullptr, nullptr};   // per queue: closest hit of each ray (t, primitive)
     float4* d_pass = nullptr;
     float4* d_image = nullptr;
     float* d_pass3 = nullptr;
@@ -164,11 +168,11 @@ gpt_status free_pixel_buffers(gpt_scene* s) {
         if (s->d_thr[k]) HIP_TRY(hipFree(s->d_thr[k]));
         s->d_ray_o[k] = s->d_ray_d[k] = s->d_thr[k] = nullptr;
     }
-    if (s->d_hit) HIP_TRY(hipFree(s->d_hit));
+    for (int i = 0; i < 2; i++) if (s->d_hit[i]) HIP_TRY(hipFree(s->d_hit[i]));
     if (s->d_pass) HIP_TRY(hipFree(s->d_pass));
     if (s->d_image) HIP_TRY(hipFree(s->d_image));
     if (s->d_pass3) HIP_TRY(hipFree(s->d_pass3));
-    s->d_hit = nullptr; s->d_pass = nullptr; s->d_image = nullptr; s->d_pass3 = nullptr;
+    s->d_hit[0] = s->d_hit[1] = nullptr; s->d_pass = nullptr; s->d_image = nullptr; s->d_pass3 = nullptr;
     s->numPixels = 0;
     return GPT_OK;
 }
@@ -233,22 +237,27 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
     if (s->profile) { gpt_status st = get_event(s, &e0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[e0], s->stream)); }
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
-    gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &cp, N, P, seed0, s->d_ray_o[0],
-                s->d_ray_d[0], s->d_thr[0], s->d_pass, counts);
+    gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, seed0,
+                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+    // every ray arrives with its closest ground / sphere hit: without triangles there is nothing to intersect
+    const bool trace = s->geom.n_tris > 0 || s->kd_stats;
     const int grid = (int)std::max<long long>(1, std::min<long long>(kTraceGrid, (total + kBlock - 1) / kBlock));
     for (int depth = 0; depth < s->params.max_depth; depth++) {
         const int in = depth & 1, out = in ^ 1;
         size_t t0 = 0, t1 = 0;
         if (s->profile) { gpt_status st = get_event(s, &t0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[t0], s->stream)); }
-        gptk_intersect(s->stream, grid, &s->geom, use_kd, s->kd_stats ? 1 : 0, depth, s->d_ray_o[in], s->d_ray_d[in],
-                       s->d_hit, counts, work, s->d_stats, s->d_spill, s->spill_stride, s->refill_below);
+        if (trace)
+            gptk_intersect(s->stream, grid, &s->geom, use_kd, s->kd_stats ? 1 : 0, depth, s->d_ray_o[in], s->d_ray_d[in],
+                           s->d_hit[in], counts, work, s->d_stats, s->d_spill, s->spill_stride, s->refill_below,
+                           s->leaf_min);
         if (s->profile) {
             gpt_status st = get_event(s, &t1); if (st) return st;
             HIP_TRY(hipEventRecord(s->ev_pool[t1], s->stream));
             s->trace_pairs.push_back({t0, t1});
         }
         gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
-                   s->d_hit, s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_pass, counts, work);
+                   s->d_hit[in], s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_hit[out], s->d_pass, counts,
+                   s->d_stats);
     }
     gptk_finish(s->stream, pixel_grid(N), N, P, s->d_pass, s->d_image, pass3);
     if (s->kd_stats) gptk_collect_wave_iters(s->stream, s->d_stats);
@@ -317,6 +326,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     s->device = device;
     s->params = rp;
     if (const char* e = getenv("GPT_REFILL_BELOW")) s->refill_below = (unsigned)std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("GPT_LEAF_MIN")) s->leaf_min = (unsigned)std::max(1, std::min(64, atoi(e)));
     gpt_status st = GPT_OK;
     do {
         if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -461,7 +471,7 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
             HIP_TRY(hipMalloc((void**)&s->d_ray_d[k], n * sizeof(float4)));
             HIP_TRY(hipMalloc((void**)&s->d_thr[k], n * sizeof(float4)));
         }
-        HIP_TRY(hipMalloc((void**)&s->d_hit, n * sizeof(float2)));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc((void**)&s->d_hit[i], n * sizeof(float2)));
         HIP_TRY(hipMalloc((void**)&s->d_pass, n * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&s->d_image, (size_t)numPixels * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&s->d_pass3, (size_t)numPixels * 3 * sizeof(float)));
@@ -610,19 +620,19 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     unsigned* counts = s->d_counters;
     unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
-    gptk_camera(s->stream, pixel_grid(N), &cp, N, 1, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0],
-                s->d_pass, counts);
+    gptk_camera(s->stream, pixel_grid(N), &s->geom, &cp, N, 1, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0],
+                s->d_thr[0], s->d_hit[0], s->d_pass, counts);
     const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
     // statistics are not touched by this query: use a scratch copy of the stats words
     unsigned long long* scratch_stats = nullptr;
     HIP_TRY(hipMalloc((void**)&scratch_stats, sizeof(unsigned long long) * GPT_STAT_WORDS));
     HIP_TRY(hipMemsetAsync(scratch_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
     const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
-    gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit, counts, work,
-                   scratch_stats, s->d_spill, s->spill_stride, s->refill_below);
+    gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit[0], counts, work,
+                   scratch_stats, s->d_spill, s->spill_stride, s->refill_below, s->leaf_min);
     HIP_TRY(hipGetLastError());
     std::vector<float> h((size_t)N * 2), ro((size_t)N * 4);
-    HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit, h.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit[0], h.size() * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(ro.data(), s->d_ray_o[0], ro.size() * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipFree(scratch_stats));

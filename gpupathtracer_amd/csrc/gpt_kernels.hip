@@ -99,6 +99,26 @@ __device__ __forceinline__ Mat load_material(const float4* __restrict__ mats, in
 }
 
 // ---------------------------------------------------------------------------
+// Closest hit among the ground plane and the spheres (traceRayKernel :509-533).
+// The kernel that CREATES a ray (k_camera, k_shade) runs this for it, with all
+// lanes busy, and stores the result in the ray's `hit` slot; the intersect
+// kernels start from that slot and only have triangles left to test.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, float& bestT, int& prim) {
+    bestT = PT_T_START;
+    prim = PT_PRIM_MISS;
+    if (g.ground_enabled) {
+        const float t = ground_t(g.ground_elevation, o, d);
+        if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
+    }
+    for (int s = 0; s < g.n_spheres; s++) {
+        const float4 sp = g.spheres[s];
+        const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
+        if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_camera: one primary ray per (pass, pixel).  A launch covers `numPasses`
 // consecutive pass counters at once.  Queue order is pixel-major: slot i holds
 // pass i % numPasses of pixel i / numPasses, so the lanes of a wave trace the
@@ -106,10 +126,12 @@ __device__ __forceinline__ Mat load_material(const float4* __restrict__ mats, in
 // rays that start from neighbouring surface points -- which keeps a wave's kd
 // traversal in the same nodes and leaves.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels, int numPasses, uint32_t seed0,
+__global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam, int numPixels, int numPasses,
+                                                      uint32_t seed0,
                                                       float4* __restrict__ ray_o,
                                                       float4* __restrict__ ray_d,
                                                       float4* __restrict__ thr,
+                                                      float2* __restrict__ hit,
                                                       float4* __restrict__ pass_rgb,
                                                       unsigned* __restrict__ counts) {
     const unsigned total = (unsigned)numPixels * (unsigned)numPasses;
@@ -123,6 +145,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels,
         st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
         st_stream(&thr[i], make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pass)));
         st_stream(&pass_rgb[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        float bestT;
+        int prim;
+        analytic_hits(g, o, d, bestT, prim);
+        st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = total;
 }
@@ -145,7 +171,9 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(CamPre cam, int numPixels,
 
 struct DevStack {
     uint32_t* lds;          // this thread's column: lds[(3*e + c) * GPT_BLOCK]
-    uint32_t* spill;        // this thread's column: spill[(3*e + c) * spill_stride]
+    // this thread's column: spill[(3*e + c) * spill_stride].  volatile keeps the (rare) spill
+    // accesses apart from the LDS ones: merged, both would become generic flat accesses
+    volatile uint32_t* spill;
     size_t spill_stride;
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
 
@@ -183,25 +211,8 @@ struct DevStack {
 };
 
 // ---------------------------------------------------------------------------
-// Closest hit among the ground plane and the spheres (traceRayKernel :509-533).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, float& bestT, int& prim) {
-    bestT = PT_T_START;
-    prim = PT_PRIM_MISS;
-    if (g.ground_enabled) {
-        const float t = ground_t(g.ground_elevation, o, d);
-        if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
-    }
-    for (int s = 0; s < g.n_spheres; s++) {
-        const float4 sp = g.spheres[s];
-        const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
-        if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // k_intersect_brute: closest hit with the reference's loop over every triangle
-// (:536-557); also the closest-hit kernel of scenes without triangles.
+// (:536-557), starting from the ray's closest ground / sphere hit.
 // ---------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, int depth,
@@ -212,7 +223,6 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
                                                                unsigned* __restrict__ work,
                                                                unsigned long long* __restrict__ stats) {
     const unsigned n = counts[depth];
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
     uint32_t cTris = 0, cHits = 0;
     // every ray costs the same here, so the queue is split statically (no work counter)
     const unsigned stride = gridDim.x * GPT_BLOCK;
@@ -222,16 +232,17 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
             const float4 rd = ld_stream(&ray_d[i]);
             const V3 o = v3(ro.x, ro.y, ro.z);
             const V3 d = v3(rd.x, rd.y, rd.z);
-            float bestT;
-            int prim;
-            analytic_hits(g, o, d, bestT, prim);
+            const float2 h = hit[i];            // closest among ground and spheres
+            int prim = __float_as_int(h.y);
             if (g.n_tris > 0) {
-                float bt = bestT;
+                float bt = h.x;
                 int bi = -1;
                 brute_closest_hit<STATS>(g.tris, g.n_tris, o, d, bt, bi, cTris);
-                if (bi >= 0) { bestT = bt; prim = bi; }
+                if (bi >= 0) {
+                    prim = bi;
+                    hit[i] = make_float2(bt, __int_as_float(bi));
+                }
             }
-            st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
             if (STATS && prim != PT_PRIM_MISS) cHits++;
         }
     }
@@ -245,20 +256,41 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
 // k_intersect_kd: closest hit with kd-tree traversal.
 //
 // Rays differ widely in traversal length (most miss the mesh's box at once, a
-// few walk hundreds of nodes), so a wave does not own a fixed set of 64 rays.
-// Each lane holds a resumable traversal cursor; the wave alternates between
+// few walk hundreds of nodes), and the kernel is bound by VALU issue: every
+// wave instruction costs the same whether 64 lanes or 5 take part.  So a wave
+// neither owns a fixed set of 64 rays nor lets each lane loop over its own
+// leaf.  Each lane holds a resumable traversal cursor; the wave alternates
+// between three phases:
 //   refill:   idle lanes take the next rays of the global work queue (one
-//             atomic per wave for all idle lanes: ballot + prefix count), test
-//             ground and spheres, and either finish at once (ray misses the
-//             root box) or start a traversal;
-//   traverse: lanes advance leaf by leaf (KdCursor::advance) until fewer than
-//             `refill_below` lanes are still busy, then the wave goes back to refill.
-//             (Variants that bound the work per lane per round -- one node or one
-//             triangle, or up to 3..12 nodes + 1..4 triangles -- raise SIMD utilisation
-//             of the loops but measured within +-5 % of this one: the kernel is bound
-//             by L1 miss handling, not by VALU issue.)
+//             atomic per wave per 512 rays, ballot + prefix count per round)
+//             together with their closest ground / sphere hit, and either
+//             finish at once (ray misses the root box) or start a traversal;
+//   walk:     lanes that stand at an inner node take one step each per
+//             iteration; a lane that reaches a leaf with triangles parks there,
+//             an empty leaf sends it straight to its next deferred interval.
+//             The phase ends when no lane walks any more or `leaf_min` lanes
+//             are parked;
+//   test:     the (ray, triangle) pairs of all parked lanes are enumerated
+//             wave-wide (prefix sum of the leaves' counts) and dealt out 64 at
+//             a time to ALL lanes: lane j tests pair base+j, fetching the
+//             owner's ray through ds_bpermute, and folds a hit into the owner's
+//             best with an LDS 64-bit atomic min on (t bits, index + 1) -- which
+//             is exactly the reference's rule: smallest t, ties to the lowest
+//             triangle index, and a triangle never displaces a ground / sphere
+//             hit at the same t (their key has 0 in the low word).
 // Once the queue is drained the remaining lanes simply run to completion.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long hit_key(float t, int tri) {
+    return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)(tri + 1);
+}
+
+__device__ __forceinline__ int bperm(unsigned byte_addr, int v) {
+    return __builtin_amdgcn_ds_bpermute((int)byte_addr, v);
+}
+__device__ __forceinline__ float bperm(unsigned byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_addr, __float_as_int(v)));
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(DevGeometry g, int depth,
                                                             const float4* __restrict__ ray_o,
@@ -268,22 +300,37 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             unsigned* __restrict__ work,
                                                             unsigned long long* __restrict__ stats,
                                                             uint32_t* __restrict__ spill, size_t spill_stride,
-                                                            unsigned refill_below) {
+                                                            unsigned refill_below, unsigned leaf_min) {
     __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
+    __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
     const unsigned n = counts[depth];
-    if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
 
     KdCursor<DevStack, STATS> cur;
     cur.st.lds = s_stack + threadIdx.x;
     cur.st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
     cur.st.spill_stride = spill_stride;
     cur.st.reset();
+    const unsigned lane = lane_id();
+    const unsigned wave_base = threadIdx.x & ~63u;
 
     uint32_t cNodes = 0, cTris = 0, cHits = 0, cBusy = 0, cRounds = 0;
     bool have = false;          // this lane holds an unfinished traversal
+    bool parked = false;        // ... and stands at a leaf whose triangles wait for the test phase
     bool drained = false;       // wave-uniform: the work queue is exhausted
     unsigned slot = 0;          // queue slot of the ray this lane is tracing
     int prim0 = PT_PRIM_MISS;   // best among ground / spheres for that ray
+    unsigned leafFirst = 0, leafCount = 0;
+
+    // The traversal of this lane is over: a triangle that beat the ground / sphere hit
+    // replaces it in the ray's hit slot.
+#define KD_FINISH()                                                                                      \
+    do {                                                                                                 \
+        const unsigned long long key_ = __atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED);            \
+        const unsigned lo_ = (unsigned)key_;                                                             \
+        if (lo_) hit[slot] = make_float2(__uint_as_float((unsigned)(key_ >> 32)), __int_as_float((int)(lo_ - 1u))); \
+        if (STATS && (lo_ || prim0 != PT_PRIM_MISS)) cHits++;                                            \
+        have = false;                                                                                    \
+    } while (0)
 
     // The wave takes rays from the global queue KD_FETCH_CHUNK at a time (one atomic on
     // the shared counter per chunk) and hands them to idle lanes from that local range.
@@ -310,16 +357,15 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                     const float4 rd = ld_stream(&ray_d[i]);
                     const V3 o = v3(ro.x, ro.y, ro.z);
                     const V3 d = v3(rd.x, rd.y, rd.z);
-                    float bestT;
-                    int prim;
-                    analytic_hits(g, o, d, bestT, prim);
-                    if (cur.begin(g.kd, o, d, bestT)) {
+                    const float2 h = hit[i];    // closest among ground and spheres
+                    const int prim = __float_as_int(h.y);
+                    if (cur.begin(g.kd, o, d, h.x)) {
                         have = true;
                         slot = i;
                         prim0 = prim;
-                    } else {
-                        st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
-                        if (STATS && prim != PT_PRIM_MISS) cHits++;
+                        s_best[threadIdx.x] = hit_key(h.x, -1);
+                    } else if (STATS && prim != PT_PRIM_MISS) {
+                        cHits++;
                     }
                 }
             }
@@ -329,18 +375,75 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             if (drained) break;
             continue;
         }
-        // ---- traverse ----
-        while (have) {
-            if (STATS) { cBusy++; if (prefix_count(__ballot(1)) == 0u) cRounds++; }
-            if (cur.advance(g.kd, cNodes, cTris)) {
-                const int prim = cur.bestTri >= 0 ? cur.bestTri : prim0;
-                st_stream(&hit[slot], make_float2(cur.bestT, __int_as_float(prim)));
-                if (STATS && prim != PT_PRIM_MISS) cHits++;
-                have = false;
+        // ---- walk ----
+        bool test_now;
+        for (;;) {
+            if (have && !parked) {
+                if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
+                const KdNode w = g.kd.nodes[cur.node];
+                if ((w.w0 & 3u) != 3u) {
+                    cur.node_step(g.kd, w);
+                } else if (w.w1 != 0u) {
+                    leafFirst = w.w0 >> 2;
+                    leafCount = w.w1;
+                    parked = true;
+                } else if (!cur.next_interval()) {
+                    KD_FINISH();
+                }
             }
-            if (!drained && (unsigned)__popcll(__ballot(have)) < refill_below) break;
+            const unsigned nPark = (unsigned)__popcll(__ballot(parked));
+            const unsigned nHave = (unsigned)__popcll(__ballot(have));
+            if (STATS) { if (have) cBusy++; if (lane == 0) cRounds++; }
+            test_now = (nPark == nHave) || (nPark >= leaf_min);
+            if (test_now) break;
+            if (!drained && nHave < refill_below) break;
+        }
+        if (!test_now) continue;
+        // ---- test ----
+        {
+            const unsigned cnt = parked ? leafCount : 0u;
+            unsigned incl = cnt;
+#pragma unroll
+            for (unsigned off = 1; off < 64; off <<= 1) {
+                const unsigned v = (unsigned)bperm((lane - off) << 2, (int)incl);
+                if (lane >= off) incl += v;
+            }
+            const unsigned excl = incl - cnt;
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            for (unsigned base = 0; base < total; base += 64) {
+                if (STATS) PT_COUNT_WAVE_ITERATION(1);
+                const unsigned p = base + lane;
+                // owner = last lane whose first pair number is <= p
+                unsigned L = 0;
+#pragma unroll
+                for (unsigned s = 32; s > 0; s >>= 1) {
+                    const unsigned c = L + s;
+                    const unsigned e = (unsigned)bperm(c << 2, (int)excl);
+                    if (e <= p) L = c;
+                }
+                const unsigned la = L << 2;
+                const unsigned k = p - (unsigned)bperm(la, (int)excl);
+                const unsigned first = (unsigned)bperm(la, (int)leafFirst);
+                const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
+                const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
+                if (p < total) {
+                    V3 a, e1, e2;
+                    const size_t rec = g.kd.refs ? (size_t)g.kd.refs[first + k] : (size_t)first + k;
+                    const int idx = load_tri(g.kd.leaf_tris, rec, a, e1, e2);
+                    float t;
+                    if (STATS) cTris++;
+                    if (triangle_t(a, e1, e2, o, d, t) && t > 0.0f) atomicMin(&s_best[wave_base + L], hit_key(t, idx));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (parked) {
+                parked = false;
+                cur.bestT = __uint_as_float((unsigned)(__atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED) >> 32));
+                if (!cur.next_interval()) KD_FINISH();
+            }
         }
     }
+#undef KD_FINISH
     if (STATS) {
         atomicAdd(&stats[GPT_STAT_KD_NODES], (unsigned long long)cNodes);
         atomicAdd(&stats[GPT_STAT_KD_TRIS], (unsigned long long)cTris);
@@ -374,8 +477,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
                                                      float4* __restrict__ out_o,
                                                      float4* __restrict__ out_d,
                                                      float4* __restrict__ out_thr,
+                                                     float2* __restrict__ out_hit,
                                                      float4* __restrict__ pass_rgb,
-                                                     unsigned* __restrict__ counts) {
+                                                     unsigned* __restrict__ counts,
+                                                     unsigned long long* __restrict__ stats) {
     __shared__ float4 s_o[SHADE_STAGE];
     __shared__ float4 s_d[SHADE_STAGE];
     __shared__ float4 s_t[SHADE_STAGE];
@@ -383,8 +488,20 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
     __shared__ unsigned s_base;
 
     const unsigned n = counts[depth];
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
+    // a surviving path leaves with its new ray and that ray's closest ground / sphere hit
+    auto emit = [&](unsigned pos, unsigned k) {
+        const float4 ro = s_o[k], rd = s_d[k];
+        st_stream(&out_o[pos], ro);
+        st_stream(&out_d[pos], rd);
+        st_stream(&out_thr[pos], s_t[k]);
+        float bestT;
+        int prim;
+        analytic_hits(g, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), bestT, prim);
+        st_stream(&out_hit[pos], make_float2(bestT, __int_as_float(prim)));
+    };
     unsigned staged = 0;                        // block-uniform: survivors waiting in LDS
     const unsigned stride = gridDim.x * GPT_BLOCK;
     for (unsigned tile = blockIdx.x * GPT_BLOCK; tile < n; tile += stride) {
@@ -466,11 +583,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
             __syncthreads();
             const unsigned base = s_base;
 #pragma unroll
-            for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += GPT_BLOCK) {
-                st_stream(&out_o[base + k], s_o[k]);
-                st_stream(&out_d[base + k], s_d[k]);
-                st_stream(&out_thr[base + k], s_t[k]);
-            }
+            for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += GPT_BLOCK) emit(base + k, k);
             // move the remainder (< 256 entries) to the front
             const unsigned rem = staged - SHADE_FLUSH;
             float4 ko = make_float4(0, 0, 0, 0), kd_ = ko, kt = ko;
@@ -494,11 +607,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams 
         if (threadIdx.x == 0) s_base = atomicAdd(&counts[depth + 1], staged);
         __syncthreads();
         const unsigned base = s_base;
-        for (unsigned k = threadIdx.x; k < staged; k += GPT_BLOCK) {
-            st_stream(&out_o[base + k], s_o[k]);
-            st_stream(&out_d[base + k], s_d[k]);
-            st_stream(&out_thr[base + k], s_t[k]);
-        }
+        for (unsigned k = threadIdx.x; k < staged; k += GPT_BLOCK) emit(base + k, k);
     }
 }
 
@@ -583,22 +692,24 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_checksum(const uint32_t* __restri
 // ---------------------------------------------------------------------------
 extern "C" {
 
-void gptk_camera(hipStream_t s, int grid, const CamPre* cam, int numPixels, int numPasses, uint32_t seed0,
-                 float4* ray_o, float4* ray_d, float4* thr, float4* pass_rgb, unsigned* counts) {
-    hipLaunchKernelGGL(k_camera, dim3(grid), dim3(GPT_BLOCK), 0, s, *cam, numPixels, numPasses, seed0, ray_o, ray_d,
-                       thr, pass_rgb, counts);
+void gptk_camera(hipStream_t s, int grid, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses,
+                 uint32_t seed0, float4* ray_o, float4* ray_d, float4* thr, float2* hit, float4* pass_rgb,
+                 unsigned* counts) {
+    hipLaunchKernelGGL(k_camera, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *cam, numPixels, numPasses, seed0, ray_o, ray_d,
+                       thr, hit, pass_rgb, counts);
 }
 
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
-                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below) {
+                    unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
+                    unsigned leaf_min) {
     if (use_kd) {
         if (stats_on)
             hipLaunchKernelGGL((k_intersect_kd<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
-                               counts, work, stats, spill, spill_stride, refill_below);
+                               counts, work, stats, spill, spill_stride, refill_below, leaf_min);
         else
             hipLaunchKernelGGL((k_intersect_kd<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
-                               counts, work, stats, spill, spill_stride, refill_below);
+                               counts, work, stats, spill, spill_stride, refill_below, leaf_min);
     } else {
         if (stats_on)
             hipLaunchKernelGGL((k_intersect_brute<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d,
@@ -611,10 +722,10 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
 
 void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
                 int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
-                float4* out_d, float4* out_thr, float4* pass_rgb, unsigned* counts, unsigned* work) {
-    (void)work;
+                float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
+                unsigned long long* stats) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
-                       out_o, out_d, out_thr, pass_rgb, counts);
+                       out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats);
 }
 
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,

@@ -131,41 +131,50 @@ struct KdCursor {
         return true;
     }
 
+    // One inner node `w`: chooses the child to enter (into `node`), defers the other one with
+    // its interval when the ray can reach it, and trims [tmin, tmax].
+    PT_HD void node_step(const KdView& kd, KdNode w) {
+        const int axis = (int)(w.w0 & 3u);
+        const float split = bits_to_float(w.w1);
+        const uint32_t left = w.w0 >> 2;
+        const float oa = sel3(axis, o.x, o.y, o.z);
+        const float da = sel3(axis, d.x, d.y, d.z);
+        const float ia = sel3(axis, inv.x, inv.y, inv.z);
+        // (plain '&' and '|' on purpose: every term is cheap and a short-circuit would only
+        // add branches that the lanes of a wave take differently)
+        const bool leftFirst = (oa < split) | ((oa == split) & (da <= 0.0f));
+        const uint32_t nearC = leftFirst ? left : left + 1u;
+        const uint32_t farC = leftFirst ? left + 1u : left;
+        // Four outcomes:
+        //   near only   plane beyond the interval, or behind the origin, or ray parallel
+        //               to it and outside the thickened plane
+        //   both, whole interval each   origin inside the thickened plane (the crossing may
+        //               be real or lie behind the origin), or parallel inside it
+        //   far only    plane crossed before the interval starts
+        //   both, cut   near gets [tmin, min(tmax,hi)], far gets [max(tmin,lo), tmax]
+        const bool parallel = (da == 0.0f);
+        const bool inSlab = fabsf(oa - split) <= kd.sigma;
+        const float tp = (split - oa) * ia;
+        const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
+        const float lo = tp - s, hi = tp + s;
+        const bool crossing = !parallel & !((lo > tmax) | (hi < 0.0f));   // the plane is met within the interval
+        const bool behind = lo < 0.0f;
+        const bool before = hi < tmin;
+        const bool bothWhole = (parallel & inSlab) | (crossing & behind);
+        const bool farOnly = crossing & !behind & before;
+        const bool bothCut = crossing & !behind & !before;
+        if (bothWhole | bothCut) st.push(farC, bothCut ? fmaxf(tmin, lo) : tmin, tmax);
+        node = farOnly ? farC : nearC;
+        tmax = bothCut ? fminf(tmax, hi) : tmax;
+    }
+
     // One leaf visit.  Returns true when the traversal is complete.
     PT_HD bool advance(const KdView& kd, uint32_t& nodesVisited, uint32_t& trisTested) {
         KdNode w = kd.nodes[node];
         if (STATS) nodesVisited++;
         while ((w.w0 & 3u) != 3u) {
             if (STATS) PT_COUNT_WAVE_ITERATION(0);
-            const int axis = (int)(w.w0 & 3u);
-            const float split = bits_to_float(w.w1);
-            const uint32_t left = w.w0 >> 2;
-            const float oa = sel3(axis, o.x, o.y, o.z);
-            const float da = sel3(axis, d.x, d.y, d.z);
-            const float ia = sel3(axis, inv.x, inv.y, inv.z);
-            const bool leftFirst = (oa < split) || (oa == split && da <= 0.0f);
-            const uint32_t nearC = leftFirst ? left : left + 1u;
-            const uint32_t farC = leftFirst ? left + 1u : left;
-            // The four outcomes are computed with selects (the lanes of a wave rarely agree on
-            // the outcome, and separate branches would run one after the other):
-            //   near only   plane beyond the interval, or behind the origin, or ray parallel
-            //               to it and outside the thickened plane
-            //   both, whole interval each   origin inside the thickened plane (the crossing may
-            //               be real or lie behind the origin), or parallel inside it
-            //   far only    plane crossed before the interval starts
-            //   both, cut   near gets [tmin, min(tmax,hi)], far gets [max(tmin,lo), tmax]
-            const bool parallel = (da == 0.0f);
-            const bool inSlab = fabsf(oa - split) <= kd.sigma;
-            const float tp = (split - oa) * ia;
-            const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
-            const float lo = tp - s, hi = tp + s;
-            const bool nearOnly = parallel ? !inSlab : (lo > tmax || hi < 0.0f);
-            const bool bothWhole = parallel ? inSlab : (!nearOnly && lo < 0.0f);
-            const bool farOnly = !parallel && !nearOnly && !bothWhole && hi < tmin;
-            const bool bothCut = !parallel && !nearOnly && !bothWhole && !farOnly;
-            if (bothWhole || bothCut) st.push(farC, bothCut ? fmaxf(tmin, lo) : tmin, tmax);
-            node = farOnly ? farC : nearC;
-            tmax = bothCut ? fminf(tmax, hi) : tmax;
+            node_step(kd, w);
             w = kd.nodes[node];
             if (STATS) nodesVisited++;
         }

@@ -11,8 +11,10 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 128 --warmup 0 --no-cpu-baseline $*"
 
+# ONLY="trace pmc_sq ..." restricts the run to the named passes
 run() {  # name, rocprof args...
   local name=$1; shift
+  if [ -n "${ONLY:-}" ] && ! [[ " $ONLY " == *" $name "* ]]; then return 0; fi
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
   local rc=$?
   echo "$name rc=$rc"
