@@ -376,10 +376,10 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         std::vector<int32_t> dev_refs;
         if (getenv("GPT_NO_DFS_LEAVES")) dev_refs = tree.refs;
         else gptkd::leaf_order_refs(dev_nodes, tree.refs, dev_refs);
-        // Leaf triangles: records duplicated in leaf order while that copy stays well inside the
-        // 256 MiB Infinity Cache together with the rest of the scene; otherwise an index list
-        // into the per-triangle records (smaller footprint, one more dependent load).
-        bool leaf_order = tree.refs.size() * sizeof(TriRec) <= (size_t)160 << 20;
+        // Leaf triangles: records duplicated in leaf order (a leaf visit then costs ONE memory
+        // latency: the kernel is bound by dependent loads, not by footprint); only a copy beyond
+        // 16 GiB falls back to an index list into the per-triangle records.
+        bool leaf_order = tree.refs.size() * sizeof(TriRec) <= (size_t)16 << 30;
         if (const char* e = getenv("GPT_LEAF_ORDER")) leaf_order = atoi(e) != 0;
         std::vector<TriRec> leaf_recs;
         if (leaf_order) {
@@ -442,14 +442,14 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
 
 gpt_status gpt_scene_destroy(gpt_scene* s) {
     if (!s) return GPT_OK;
-    hipSetDevice(s->device);
-    if (s->stream) hipStreamSynchronize(s->stream);
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     free_pixel_buffers(s);
     void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_refs, s->d_tri_nm, s->d_mats, s->d_nodes,
                     s->d_spill, s->d_counters, s->d_stats};
-    for (void* p : ptrs) if (p) hipFree(p);
-    for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
-    if (s->stream) hipStreamDestroy(s->stream);
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return GPT_OK;
 }

@@ -6,11 +6,15 @@
 
 #include "kd_traverse.h"
 
-// Per-pass device counters: counts[d] = live paths entering depth d;
-// work[d] / work[SLOTS + d] = work-queue heads of the intersect / shade kernels.
+// Per-pass device counters: counts[d] = live paths entering depth d, followed by the work-queue
+// heads of the kd intersect kernel: the queue of depth d is cut into GPT_WORK_PARTS contiguous
+// parts, one per XCD, each with its own head word on its own 128-byte line
+// (work[(d * GPT_WORK_PARTS + part) * GPT_WORK_STRIDE]).
 #define GPT_MAX_DEPTH 64
 #define GPT_MAX_DEPTH_SLOTS 72
-#define GPT_COUNTER_WORDS (3 * GPT_MAX_DEPTH_SLOTS)
+#define GPT_WORK_PARTS 8
+#define GPT_WORK_STRIDE 32
+#define GPT_COUNTER_WORDS (GPT_MAX_DEPTH_SLOTS + GPT_MAX_DEPTH_SLOTS * GPT_WORK_PARTS * GPT_WORK_STRIDE)
 
 // Cumulative 64-bit statistics.
 #define GPT_STAT_LIVE0 0                      // [GPT_MAX_DEPTH] live paths per depth

@@ -171,22 +171,25 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 
 struct DevStack {
     uint32_t* lds;          // this thread's column: lds[(3*e + c) * GPT_BLOCK]
-    // this thread's column: spill[(3*e + c) * spill_stride].  volatile keeps the (rare) spill
-    // accesses apart from the LDS ones: merged, both would become generic flat accesses
-    volatile uint32_t* spill;
+    uint32_t* spill;        // this thread's column: spill[(3*e + c) * spill_stride]
     size_t spill_stride;
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
 
+    // The spill path uses non-temporal accesses: written once, read once -- and a different
+    // kind of access than the LDS path's, so the compiler cannot merge the two into generic
+    // flat accesses.
     __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
-        if (sp - lo == KD_LDS_N) {
-            const int slot = lo & (KD_LDS_N - 1);
-            spill[(size_t)(3 * lo + 0) * spill_stride] = lds[(3 * slot + 0) * GPT_BLOCK];
-            spill[(size_t)(3 * lo + 1) * spill_stride] = lds[(3 * slot + 1) * GPT_BLOCK];
-            spill[(size_t)(3 * lo + 2) * spill_stride] = lds[(3 * slot + 2) * GPT_BLOCK];
+        const int slot = sp & (KD_LDS_N - 1);
+        if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
+#ifdef KD_SPILL_PROBE   // experiment: how many wave iterations execute this block
+            PT_COUNT_WAVE_ITERATION(1);
+#endif
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                __builtin_nontemporal_store(lds[(3 * slot + c) * GPT_BLOCK], spill + (size_t)(3 * lo + c) * spill_stride);
             lo++;
         }
-        const int slot = sp & (KD_LDS_N - 1);
         lds[(3 * slot + 0) * GPT_BLOCK] = node;
         lds[(3 * slot + 1) * GPT_BLOCK] = __float_as_uint(tmin);
         lds[(3 * slot + 2) * GPT_BLOCK] = __float_as_uint(tmax);
@@ -195,16 +198,20 @@ struct DevStack {
     __device__ __forceinline__ bool pop(uint32_t& node, float& tmin, float& tmax) {
         if (sp == 0) return false;
         sp--;
+        // the LDS slot is read unconditionally (it is always a valid address) and overridden in the
+        // rare spilled case; otherwise the compiler selects between the two ADDRESSES and emits
+        // generic flat loads
+        const int slot = sp & (KD_LDS_N - 1);
+        node = lds[(3 * slot + 0) * GPT_BLOCK];
+        tmin = __uint_as_float(lds[(3 * slot + 1) * GPT_BLOCK]);
+        tmax = __uint_as_float(lds[(3 * slot + 2) * GPT_BLOCK]);
+        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // the values, not the addresses, meet below
         if (sp < lo) {
-            node = spill[(size_t)(3 * sp + 0) * spill_stride];
-            tmin = __uint_as_float(spill[(size_t)(3 * sp + 1) * spill_stride]);
-            tmax = __uint_as_float(spill[(size_t)(3 * sp + 2) * spill_stride]);
+            node = __builtin_nontemporal_load(spill + (size_t)(3 * sp + 0) * spill_stride);
+            tmin = __uint_as_float(__builtin_nontemporal_load(spill + (size_t)(3 * sp + 1) * spill_stride));
+            tmax = __uint_as_float(__builtin_nontemporal_load(spill + (size_t)(3 * sp + 2) * spill_stride));
+            asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // wait here, in the rare branch, not at a later join
             lo = sp;
-        } else {
-            const int slot = sp & (KD_LDS_N - 1);
-            node = lds[(3 * slot + 0) * GPT_BLOCK];
-            tmin = __uint_as_float(lds[(3 * slot + 1) * GPT_BLOCK]);
-            tmax = __uint_as_float(lds[(3 * slot + 2) * GPT_BLOCK]);
         }
         return true;
     }
@@ -303,6 +310,10 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             unsigned refill_below, unsigned leaf_min) {
     __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
     __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
+#ifdef KD_LDS_PAD   // occupancy experiments: extra LDS per block
+    __shared__ uint32_t s_pad[KD_LDS_PAD / 4];
+    if (depth < 0) s_pad[threadIdx.x] = spill_stride, hit[0].x = s_pad[threadIdx.x ^ 1];
+#endif
     const unsigned n = counts[depth];
 
     KdCursor<DevStack, STATS> cur;
@@ -334,6 +345,11 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 
     // The wave takes rays from the global queue KD_FETCH_CHUNK at a time (one atomic on
     // the shared counter per chunk) and hands them to idle lanes from that local range.
+    // The queue is cut into 8 contiguous parts with a head word each; a workgroup starts in the
+    // part of its XCD (blocks b and b + 8 share one, and with it an L2: rays that are neighbours
+    // in the queue -- neighbouring pixels -- then warm the same L2) and moves on to the other
+    // parts when its own is exhausted.
+    unsigned part = blockIdx.x & (GPT_WORK_PARTS - 1u), parts_done = 0;
     unsigned local_next = 0, local_end = 0;
     for (;;) {
         // ---- refill ----
@@ -342,10 +358,18 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             const unsigned cnt = (unsigned)__popcll(idle);
             if (cnt == 0u || (64u - cnt) >= refill_below) break;
             if (local_next >= local_end) {
-                const unsigned base = wave_fetch(&work[depth], KD_FETCH_CHUNK);
-                if (base >= n) { drained = true; break; }
+                // next chunk of the current part of the queue; an exhausted part is left for good
+                const unsigned part_lo = (unsigned)((unsigned long long)n * part / GPT_WORK_PARTS);
+                const unsigned part_hi = (unsigned)((unsigned long long)n * (part + 1u) / GPT_WORK_PARTS);
+                const unsigned base = part_lo + wave_fetch(&work[(depth * GPT_WORK_PARTS + part) * GPT_WORK_STRIDE],
+                                                           KD_FETCH_CHUNK);
+                if (base >= part_hi) {
+                    part = (part + 1u) & (GPT_WORK_PARTS - 1u);
+                    if (++parts_done == GPT_WORK_PARTS) drained = true;
+                    continue;
+                }
                 local_next = base;
-                local_end = (base + KD_FETCH_CHUNK < n) ? base + KD_FETCH_CHUNK : n;
+                local_end = (base + KD_FETCH_CHUNK < part_hi) ? base + KD_FETCH_CHUNK : part_hi;
             }
             const unsigned avail = local_end - local_next;
             const unsigned take = cnt < avail ? cnt : avail;
@@ -357,7 +381,10 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                     const float4 rd = ld_stream(&ray_d[i]);
                     const V3 o = v3(ro.x, ro.y, ro.z);
                     const V3 d = v3(rd.x, rd.y, rd.z);
-                    const float2 h = hit[i];    // closest among ground and spheres
+                    float2 h = hit[i];          // closest among ground and spheres
+                    // (consumed here: a load still pending when the walk resumes would make every
+                    // later wait a wait for ALL outstanding loads)
+                    asm volatile("" : "+v"(h.x), "+v"(h.y));
                     const int prim = __float_as_int(h.y);
                     if (cur.begin(g.kd, o, d, h.x)) {
                         have = true;
@@ -411,7 +438,9 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             const unsigned excl = incl - cnt;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             for (unsigned base = 0; base < total; base += 64) {
+#ifndef KD_SPILL_PROBE
                 if (STATS) PT_COUNT_WAVE_ITERATION(1);
+#endif
                 const unsigned p = base + lane;
                 // owner = last lane whose first pair number is <= p
                 unsigned L = 0;
@@ -427,9 +456,15 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
                 const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
                 if (p < total) {
-                    V3 a, e1, e2;
                     const size_t rec = g.kd.refs ? (size_t)g.kd.refs[first + k] : (size_t)first + k;
-                    const int idx = load_tri(g.kd.leaf_tris, rec, a, e1, e2);
+                    // the whole record at once (left alone, the compiler fetches `a` only after the
+                    // determinant test: a second memory latency in every chunk)
+                    const float4* rp = reinterpret_cast<const float4*>(g.kd.leaf_tris + rec);
+                    float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                    asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z),
+                                 "+v"(r1.w), "+v"(r2.x), "+v"(r2.y));
+                    const V3 a = v3(r0.x, r0.y, r0.z), e1 = v3(r0.w, r1.x, r1.y), e2 = v3(r1.z, r1.w, r2.x);
+                    const int idx = __float_as_int(r2.y);
                     float t;
                     if (STATS) cTris++;
                     if (triangle_t(a, e1, e2, o, d, t) && t > 0.0f) atomicMin(&s_best[wave_base + L], hit_key(t, idx));
