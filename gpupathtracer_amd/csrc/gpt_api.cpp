@@ -135,8 +135,8 @@ struct gpt_scene {
     // per-pixel / per-path buffers
     int numPixels = 0;
     int batch = 1;                           // passes traced together per launch
-    unsigned refill_below = 48;              // k_intersect_kd: refill a wave when fewer lanes are busy
-    unsigned leaf_min = 24;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
+    unsigned refill_below = 52;              // k_intersect_kd: refill a wave when fewer lanes are busy
+    unsigned leaf_min = 28;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};
@@ -401,6 +401,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
 
         s->spill_stride = (size_t)kTraceGrid * kBlock;
         const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
+        if (spill_words >> 32) { st = fail(GPT_ERR_TOO_LARGE, "kd-tree too deep for the traversal stack"); break; }
         if (hipMalloc((void**)&s->d_spill, spill_words * 4) != hipSuccess) { st = fail(GPT_ERR_OUT_OF_MEMORY, "spill buffer"); break; }
         if (hipMalloc((void**)&s->d_counters, sizeof(unsigned) * GPT_COUNTER_WORDS) != hipSuccess ||
             hipMalloc((void**)&s->d_stats, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) {

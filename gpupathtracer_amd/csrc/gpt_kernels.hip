@@ -172,7 +172,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 struct DevStack {
     uint32_t* lds;          // this thread's column: lds[(3*e + c) * GPT_BLOCK]
     uint32_t* spill;        // this thread's column: spill[(3*e + c) * spill_stride]
-    size_t spill_stride;
+    unsigned spill_stride;  // (3 * depth * stride fits 32 bits: checked by the host)
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
 
     // The spill path uses non-temporal accesses: written once, read once -- and a different
@@ -187,7 +187,7 @@ struct DevStack {
 #endif
 #pragma unroll
             for (int c = 0; c < 3; c++)
-                __builtin_nontemporal_store(lds[(3 * slot + c) * GPT_BLOCK], spill + (size_t)(3 * lo + c) * spill_stride);
+                __builtin_nontemporal_store(lds[(3 * slot + c) * GPT_BLOCK], spill + (unsigned)(3 * lo + c) * spill_stride);
             lo++;
         }
         lds[(3 * slot + 0) * GPT_BLOCK] = node;
@@ -207,9 +207,9 @@ struct DevStack {
         tmax = __uint_as_float(lds[(3 * slot + 2) * GPT_BLOCK]);
         asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // the values, not the addresses, meet below
         if (sp < lo) {
-            node = __builtin_nontemporal_load(spill + (size_t)(3 * sp + 0) * spill_stride);
-            tmin = __uint_as_float(__builtin_nontemporal_load(spill + (size_t)(3 * sp + 1) * spill_stride));
-            tmax = __uint_as_float(__builtin_nontemporal_load(spill + (size_t)(3 * sp + 2) * spill_stride));
+            node = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 0) * spill_stride);
+            tmin = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 1) * spill_stride));
+            tmax = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride));
             asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // wait here, in the rare branch, not at a later join
             lo = sp;
         }
@@ -273,8 +273,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
 //             together with their closest ground / sphere hit, and either
 //             finish at once (ray misses the root box) or start a traversal;
 //   walk:     lanes that stand at an inner node take one step each per
-//             iteration; a lane that reaches a leaf with triangles parks there,
-//             an empty leaf sends it straight to its next deferred interval.
+//             iteration; a lane that reaches a leaf (empty or not) parks there.
 //             The phase ends when no lane walks any more or `leaf_min` lanes
 //             are parked;
 //   test:     the (ray, triangle) pairs of all parked lanes are enumerated
@@ -284,7 +283,8 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
 //             best with an LDS 64-bit atomic min on (t bits, index + 1) -- which
 //             is exactly the reference's rule: smallest t, ties to the lowest
 //             triangle index, and a triangle never displaces a ground / sphere
-//             hit at the same t (their key has 0 in the low word).
+//             hit at the same t (their key has 0 in the low word).  Then the
+//             parked lanes move on to their next deferred interval or finish.
 // Once the queue is drained the remaining lanes simply run to completion.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long hit_key(float t, int tri) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     KdCursor<DevStack, STATS> cur;
     cur.st.lds = s_stack + threadIdx.x;
     cur.st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
-    cur.st.spill_stride = spill_stride;
+    cur.st.spill_stride = (unsigned)spill_stride;
     cur.st.reset();
     const unsigned lane = lane_id();
     const unsigned wave_base = threadIdx.x & ~63u;
@@ -398,34 +398,30 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             }
             local_next += take;
         }
-        if (__ballot(have) == 0ull) {
+        const unsigned nHave = (unsigned)__popcll(__ballot(have));
+        if (nHave == 0u) {
             if (drained) break;
             continue;
         }
         // ---- walk ----
-        bool test_now;
+        // (kept minimal: this loop runs once per tree level; everything that happens once per
+        // leaf -- next interval, end of traversal -- is left to the test phase)
         for (;;) {
             if (have && !parked) {
                 if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
                 const KdNode w = g.kd.nodes[cur.node];
                 if ((w.w0 & 3u) != 3u) {
                     cur.node_step(g.kd, w);
-                } else if (w.w1 != 0u) {
+                } else {
                     leafFirst = w.w0 >> 2;
-                    leafCount = w.w1;
+                    leafCount = w.w1;     // may be 0: an empty leaf
                     parked = true;
-                } else if (!cur.next_interval()) {
-                    KD_FINISH();
                 }
             }
             const unsigned nPark = (unsigned)__popcll(__ballot(parked));
-            const unsigned nHave = (unsigned)__popcll(__ballot(have));
             if (STATS) { if (have) cBusy++; if (lane == 0) cRounds++; }
-            test_now = (nPark == nHave) || (nPark >= leaf_min);
-            if (test_now) break;
-            if (!drained && nHave < refill_below) break;
+            if (nPark == nHave || nPark >= leaf_min) break;
         }
-        if (!test_now) continue;
         // ---- test ----
         {
             const unsigned cnt = parked ? leafCount : 0u;
@@ -683,7 +679,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_debug_intersect(DevGeometry g, co
     DevStack st;
     st.lds = s_stack + threadIdx.x;
     st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
-    st.spill_stride = spill_stride;
+    st.spill_stride = (unsigned)spill_stride;
     st.reset();
     const int stride = gridDim.x * GPT_BLOCK;
     uint32_t c0 = 0, c1 = 0;
