@@ -38,8 +38,6 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
                 unsigned long long* stats);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
-void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
-                          int32_t* tri, float* t_out, uint32_t* spill, size_t spill_stride);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
 }
@@ -648,26 +646,67 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     return GPT_OK;
 }
 
+// Closest triangle for caller-supplied rays, through the SAME intersect kernels a render pass
+// launches: the rays are laid out as a path queue of depth 0 whose hit slots start at "nothing hit".
 gpt_status gpt_debug_intersect(gpt_scene* s, const float* rays, int n, int use_kdtree, int32_t* tri, float* t) {
     if (!s || !rays || !tri || !t || n < 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
     if (n == 0) return GPT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    float* d_rays = nullptr; int32_t* d_tri = nullptr; float* d_t = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 24));
-    HIP_TRY(hipMalloc((void**)&d_tri, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&d_t, (size_t)n * 4));
-    HIP_TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
-    const int grid = std::max(1, std::min(kTraceGrid, (n + kBlock - 1) / kBlock));
-    gptk_debug_intersect(s->stream, grid, &s->geom, use_kdtree ? 1 : 0, d_rays, n, d_tri, d_t, s->d_spill,
-                         s->spill_stride);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipFree(d_rays));
-    HIP_TRY(hipFree(d_tri));
-    HIP_TRY(hipFree(d_t));
-    return GPT_OK;
+    if (s->geom.n_tris == 0) {
+        for (int i = 0; i < n; i++) { tri[i] = -1; t[i] = PT_T_START; }
+        return GPT_OK;
+    }
+    std::vector<float> ho((size_t)n * 4), hd((size_t)n * 4), hh((size_t)n * 2);
+    const int miss = PT_PRIM_MISS;
+    for (int i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) {
+            ho[4 * (size_t)i + c] = rays[6 * (size_t)i + c];
+            hd[4 * (size_t)i + c] = rays[6 * (size_t)i + 3 + c];
+        }
+        memcpy(&ho[4 * (size_t)i + 3], &i, 4);
+        memcpy(&hd[4 * (size_t)i + 3], &miss, 4);
+        hh[2 * (size_t)i] = PT_T_START;
+        memcpy(&hh[2 * (size_t)i + 1], &miss, 4);
+    }
+    float4 *d_o = nullptr, *d_d = nullptr;
+    float2* d_h = nullptr;
+    unsigned* d_cnt = nullptr;
+    unsigned long long* d_st = nullptr;
+    gpt_status st = GPT_OK;
+    do {
+        if (hipMalloc((void**)&d_o, (size_t)n * 16) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * 16) != hipSuccess ||
+            hipMalloc((void**)&d_h, (size_t)n * 8) != hipSuccess ||
+            hipMalloc((void**)&d_cnt, sizeof(unsigned) * GPT_COUNTER_WORDS) != hipSuccess ||
+            hipMalloc((void**)&d_st, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) {
+            st = fail(GPT_ERR_OUT_OF_MEMORY, "debug intersect buffers");
+            break;
+        }
+        const unsigned un = (unsigned)n;
+        if (hipMemcpyAsync(d_o, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+            hipMemcpyAsync(d_d, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+            hipMemcpyAsync(d_h, hh.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+            hipMemsetAsync(d_cnt, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream) != hipSuccess ||
+            hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream) != hipSuccess ||
+            hipMemcpyAsync(d_cnt, &un, 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+            st = fail(GPT_ERR_HIP, "debug intersect upload");
+            break;
+        }
+        const int grid = std::max(1, std::min(kTraceGrid, (n + kBlock - 1) / kBlock));
+        gptk_intersect(s->stream, grid, &s->geom, use_kdtree ? 1 : 0, 0, 0, d_o, d_d, d_h, d_cnt, d_cnt + GPT_MAX_DEPTH_SLOTS,
+                       d_st, s->d_spill, s->spill_stride, s->refill_below, s->leaf_min);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(hh.data(), d_h, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+            hipStreamSynchronize(s->stream) != hipSuccess) {
+            st = fail(GPT_ERR_HIP, "debug intersect launch");
+            break;
+        }
+        for (int i = 0; i < n; i++) {
+            t[i] = hh[2 * (size_t)i];
+            memcpy(&tri[i], &hh[2 * (size_t)i + 1], 4);
+        }
+    } while (0);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_cnt); (void)hipFree(d_st);
+    return st;
 }
 
 // ---- kd-tree builder through the C-ABI ----------------------------------------

@@ -668,35 +668,8 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPass
 }
 
 // ---------------------------------------------------------------------------
-// Debug / parity kernels
+// Instrumentation and the scene checksum
 // ---------------------------------------------------------------------------
-// Closest triangle for caller-supplied rays (no ground, no spheres).
-template <bool USE_KD>
-__global__ __launch_bounds__(GPT_BLOCK) void k_debug_intersect(DevGeometry g, const float* __restrict__ rays, int n,
-                                                               int32_t* __restrict__ tri, float* __restrict__ t_out,
-                                                               uint32_t* __restrict__ spill, size_t spill_stride) {
-    __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
-    DevStack st;
-    st.lds = s_stack + threadIdx.x;
-    st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
-    st.spill_stride = (unsigned)spill_stride;
-    st.reset();
-    const int stride = gridDim.x * GPT_BLOCK;
-    uint32_t c0 = 0, c1 = 0;
-    for (int i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < n; i += stride) {
-        const V3 o = v3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]);
-        const V3 d = v3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]);
-        float bt = PT_T_START;
-        int bi = -1;
-        if (g.n_tris > 0) {
-            if (USE_KD) kd_closest_hit<DevStack, false>(g.kd, o, d, bt, bi, st, c0, c1);
-            else brute_closest_hit<false>(g.tris, g.n_tris, o, d, bt, bi, c1);
-        }
-        tri[i] = bi;
-        t_out[i] = bt;
-    }
-}
-
 __global__ void k_collect_wave_iters(unsigned long long* stats) {
     if (threadIdx.x < 2) {
         stats[GPT_STAT_WAVE_ITERS_NODE + threadIdx.x] += g_wave_iters[threadIdx.x];
@@ -762,16 +735,6 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3) {
     hipLaunchKernelGGL(k_finish, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass_rgb, image, pass_out3);
-}
-
-void gptk_debug_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, const float* rays, int n,
-                          int32_t* tri, float* t_out, uint32_t* spill, size_t spill_stride) {
-    if (use_kd)
-        hipLaunchKernelGGL((k_debug_intersect<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, rays, n, tri, t_out,
-                           spill, spill_stride);
-    else
-        hipLaunchKernelGGL((k_debug_intersect<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, rays, n, tri, t_out,
-                           spill, spill_stride);
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {

@@ -159,6 +159,39 @@ def test_kdtree_equals_brute_force_on_device():
     assert np.array_equal(to, tb[sub]) and np.array_equal(tto.view(np.int32), ttb[sub].view(np.int32))
 
 
+@pytest.mark.parametrize("small", [2, 64, 4096])
+def test_kd_kernel_leaf_sizes_and_duplicate_triangles(small):
+    """The wave-cooperative triangle phase: leaves far larger than a 64-pair chunk (threshold 4096),
+    tiny leaves, and a mesh in which every triangle exists twice (equal t: the lower index wins)."""
+    v, n = meshes.load_asset("monkey")
+    v2 = np.concatenate([v, v]).astype(np.float32)
+    n2 = np.concatenate([n, n]).astype(np.float32)
+    polys = meshes.polys_from_triangles(v2, n2, S.MATERIALS["glass"])
+    rng = np.random.default_rng(11 + small)
+    m = 120000
+    pts = v.reshape(-1, 3)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    ctr, ext = (lo + hi) / 2, (hi - lo).max()
+    o = ((rng.random((m, 3), dtype=np.float32) * 3 - 1.5) * ext + ctr).astype(np.float32)
+    tgt = pts[rng.integers(0, pts.shape[0], m)] + ((rng.random((m, 3), dtype=np.float32) - 0.5) * 0.05 * ext)
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    rays[:64, 3:] = np.nan                                  # rays the reference's loop can never hit with
+    with api.Scene(None, polys, api.render_params(max_depth=1, kd_small_threshold=small)) as sc:
+        tk, ttk = sc.intersect(rays, use_kdtree=True)
+        tb, ttb = sc.intersect(rays, use_kdtree=False)
+    hit = tb >= 0
+    assert hit.sum() > m // 3 and (tb[:64] == -1).all()
+    assert np.array_equal(tk, tb)
+    assert np.array_equal(ttk.view(np.int32), ttb.view(np.int32))
+    # duplicates: the winner is always the first copy
+    assert (tb[hit] < polys.size // 2).all()
+    sub = slice(0, 3000)
+    to, tto = O.closest_triangle(v2, rays[sub])
+    assert np.array_equal(to, tb[sub]) and np.array_equal(tto.view(np.int32), ttb[sub].view(np.int32))
+
+
 def test_image_accumulates_passes_in_order():
     """image += pass, float32, in counter order (path_tracer.cpp:100-103)."""
     w = h = 96
