@@ -19,7 +19,7 @@ kd-tree traversal.  Inputs (scene, tree, buffers) are resident in HBM before
 the timed region starts.
 
 Rank 0 prints one JSON line; `roofline` describes the dominant kernel
-(k_intersect, the kd-tree traversal) and `cpu_baseline` the CPU oracle timed on
+(k_intersect_kd, the kd-tree traversal) and `cpu_baseline` the CPU oracle timed on
 a bounded sample of the same workload.
 """
 import argparse
@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
-    ap.add_argument("--batch", type=int, default=128, help="passes traced together per launch")
+    ap.add_argument("--batch", type=int, default=256, help="passes traced together per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -191,18 +191,38 @@ def main():
 
     if rank == 0:
         n_spheres = int(spheres.size)
+        # Algorithmic bytes per path-bounce: B = B_state + B_geom, with
+        #   B_state = 124 (path state read + written once), B_geom = 8 N_nodes + 40 N_tris + 16 N_spheres + 72 [hit].
+        # The terms the kd intersect kernel itself executes are the ray it reads (24), the hit slot it
+        # reads and may rewrite (8) and the tree terms; ground / sphere tests, state and materials
+        # belong to k_camera / k_shade.  `achieved` prices the dominant kernel with ITS terms;
+        # `pass_level` prices the whole path-bounce against the whole device time.
         bytes_per_pb = 124.0 + 8.0 * nodes_per_pb + 40.0 * tris_per_pb + 16.0 * n_spheres + 72.0 * hit_frac
+        kd_bytes_per_pb = 24.0 + 8.0 + 8.0 * nodes_per_pb + 40.0 * tris_per_pb
         launches = max(1, st["trace_launches"])
-        avg_launch_s = st["device_ms_trace"] / 1e3 / launches
         pb_per_launch = st["path_bounces"] / launches
-        achieved = bytes_per_pb * pb_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        trace_share = st["device_ms_trace"] / max(1e-9, st["device_ms_total"])
+        if trace_share >= 0.5:
+            kernel, kernel_bytes = "k_intersect_kd<false>", kd_bytes_per_pb
+            avg_launch_s = st["device_ms_trace"] / 1e3 / launches
+        else:   # no (or cheap) triangle work: the shading kernel dominates; it moves everything but the tree terms
+            kernel, kernel_bytes = "k_shade", bytes_per_pb - 8.0 * nodes_per_pb - 40.0 * tris_per_pb
+            avg_launch_s = (st["device_ms_total"] - st["device_ms_trace"]) / 1e3 / launches
+        achieved = kernel_bytes * pb_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        pass_level = bytes_per_pb * st["path_bounces"] / (st["device_ms_total"] / 1e3) / 1e9 if st["device_ms_total"] > 0 else 0.0
         traffic = None
         if os.path.exists(args.traffic_file):
             try:
                 tj = json.load(open(args.traffic_file))
                 traffic = tj.get("k_intersect_hbm_bytes_per_launch")
+                # the counters were collected at one batch size: scale to this run's launch
+                ref_pb = tj.get("path_bounces_per_launch")
+                if traffic is not None and ref_pb:
+                    traffic = traffic * pb_per_launch / ref_pb
             except Exception:
                 traffic = None
+        if kernel != "k_intersect_kd<false>":
+            traffic = None
         out = {
             "metric": "Mpath-bounces/s",
             "value": total_pb / elapsed_max / 1e6,
@@ -232,21 +252,23 @@ def main():
                 "kd": dict(scene.info(), build_and_upload_s=round(t_build, 2)),
             },
             "roofline": {
-                "kernel": "k_intersect_kd<false>",
+                "kernel": kernel,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "bytes_per_path_bounce": bytes_per_pb,
+                "bytes_per_path_bounce": kernel_bytes,
+                "pass_level": {"bytes_per_path_bounce": bytes_per_pb, "achieved": pass_level,
+                               "frac": pass_level / HBM_PEAK_GBS},
                 "kd_nodes_per_path_bounce": nodes_per_pb,
                 "tris_per_path_bounce": tris_per_pb,
                 "hit_fraction": hit_frac,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": launches,
                 "path_bounces_per_launch": pb_per_launch,
-                "intersect_share_of_pass": st["device_ms_trace"] / max(1e-9, st["device_ms_total"]),
+                "intersect_share_of_pass": trace_share,
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -38,13 +38,26 @@ derived = {
     "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
     "wave_cycles_issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
     "avg_launch_us_traced": d["kernels"][key]["avg_us"],
+    # share of the SIMDs' issue slots taken by vector-ALU instructions: SQ_ACTIVE_INST_VALU counts
+    # 4-cycle slots summed over all SIMDs, GRBM_GUI_ACTIVE busy cycles summed over the 8 XCDs
+    "valu_busy": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+    "valu_insts_per_launch": c["SQ_INSTS_VALU"] / c["_dispatches"]["pmc_sq"],
+    "salu_insts_per_launch": c["SQ_INSTS_SALU"] / c["_dispatches"]["pmc_sq2"],
 }
+# the bench line of the traced run (its JSON is in the pass's log) tells how many path-bounces a launch held
+pb_per_launch = None
+for line in open(os.path.join(src, "trace.log"), errors="replace"):
+    if line.startswith("{"):
+        pb_per_launch = json.loads(line)["roofline"]["path_bounces_per_launch"]
+        shutil.copy(os.path.join(src, "trace.log"), os.path.join(out, tag + "_bench_under_trace.log"))
+derived["path_bounces_per_launch"] = pb_per_launch
 d["derived_k_intersect_kd"] = derived
 json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
 json.dump({
     "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
+    "path_bounces_per_launch": pb_per_launch,
     "how": "rocprofv3 --pmc, separate passes: sum(TCC_EA0_RDREQ_{32,64,128}B_sum x request size) + WRITE_SIZE*1024, "
-           "divided by the kernel's dispatches; bench.py --steps 128 --warmup 0 --batch 128 (8 launches of 128 passes)",
+           "divided by the kernel's dispatches; bench.py --steps 256 --warmup 0 (8 launches of 256 passes)",
     "source": tag + "_pmc_summary.json",
 }, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))
