@@ -11,8 +11,10 @@
 //   small nodes  cukd/detail/small_node_array_kernels.cu:23-91 (SAH over the
 //                triangle-box faces, cost = (nL*AL + nR*AR)/A + Ct, leaf when
 //                the best cost >= the triangle count, cukd/kdtree.cu:247-258).
-// Unlike cukd (a GPU builder with racy tie-breaks) this builder is sequential
-// and fully deterministic; ties go to the first candidate in the order
+// Unlike cukd (a GPU builder with racy tie-breaks) this builder is fully
+// deterministic -- its worker threads only take decisions that do not depend on
+// each other, numbering happens in queue order -- and ties go to the first
+// candidate in the order
 // x-min faces, x-max faces, y-min, y-max, z-min, z-max, each in triangle order.
 //
 // Output layout (see gpt.h): nodes numbered breadth-first, the two children of
@@ -23,7 +25,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <deque>
+#include <cstdlib>
+#include <thread>
+#include <vector>
 
 namespace gptkd {
 
@@ -101,6 +107,198 @@ bool clipped_bounds(const float* v9, const Box& b, double pad, float out_mn[3], 
 
 }  // namespace
 
+namespace {
+
+// What processing one queue entry decides, recorded so that it can be applied later: the
+// decisions of all entries of a tree level are independent of each other (they are taken by
+// worker threads), while node numbers and leaf reference runs are handed out afterwards, one
+// entry after the other in queue order -- the order a single-threaded breadth-first build uses.
+struct Cut { int axis; float pos; bool empty_right; };
+struct Decision {
+    int n_cuts = 0;
+    Cut cuts[6];
+    bool split = false;     // false: the (remaining) node becomes a leaf holding `w.items`
+    int axis = 0;
+    float pos = 0;
+    Work L, R;              // children of a split (items, box, stage); node / depth set on commit
+};
+
+// Runs fn(part, begin, end) over `parts` contiguous slices of [0, n), one thread each.
+template <class F>
+void parallel_slices(size_t n, int parts, F fn) {
+    std::vector<std::thread> pool;
+    for (int p = 1; p < parts; p++) pool.emplace_back([=]() { fn(p, n * (size_t)p / (size_t)parts, n * (size_t)(p + 1) / (size_t)parts); });
+    fn(0, (size_t)0, n / (size_t)parts);
+    for (std::thread& t : pool) t.join();
+}
+
+// `inner_threads` > 1: the entry is one of the few, huge ones at the top of the tree; its
+// per-triangle loops are cut into slices whose results are joined in slice order, so the outcome
+// does not depend on the thread count.
+void decide(const float* verts, const BuildParams& bp, double clip_pad, Work& w, Decision& d, int inner_threads) {
+    const int n = (int)w.items.size();
+    if (n == 0) return;
+    int depth = w.depth;
+    if (!w.small && n > bp.small_threshold && w.depth < kMaxDepth - 8) {
+        // ---------------- large-node stage ----------------
+        const int slices = (inner_threads > 1 && n >= 100000) ? inner_threads : 1;
+        Box tb;
+        for (int k = 0; k < 3; k++) { tb.mn[k] = INFINITY; tb.mx[k] = -INFINITY; }
+        {
+            std::vector<Box> part((size_t)slices, tb);
+            parallel_slices((size_t)n, slices, [&](int p, size_t b, size_t e) {
+                Box pb = part[(size_t)p];
+                for (size_t i = b; i < e; i++)
+                    for (int k = 0; k < 3; k++) {
+                        pb.mn[k] = std::min(pb.mn[k], w.items[i].mn[k]);
+                        pb.mx[k] = std::max(pb.mx[k], w.items[i].mx[k]);
+                    }
+                part[(size_t)p] = pb;
+            });
+            for (const Box& pb : part)          // min / max: exact, any order
+                for (int k = 0; k < 3; k++) {
+                    tb.mn[k] = std::min(tb.mn[k], pb.mn[k]);
+                    tb.mx[k] = std::max(tb.mx[k], pb.mx[k]);
+                }
+        }
+        // empty-space cuts, thresholds from the incoming box
+        for (int a = 0; a < 3; a++) {
+            float thr = kEmptyRatio * (w.box.mx[a] - w.box.mn[a]);
+            if ((w.box.mx[a] - tb.mx[a]) - thr > 0) { d.cuts[d.n_cuts++] = {a, tb.mx[a], true}; depth++; }   // right child empty
+            if ((tb.mn[a] - w.box.mn[a]) - thr > 0) { d.cuts[d.n_cuts++] = {a, tb.mn[a], false}; depth++; }  // left child empty
+        }
+        // spatial median of the tight box on its longest axis
+        float dx = tb.mx[0] - tb.mn[0], dy = tb.mx[1] - tb.mn[1], dz = tb.mx[2] - tb.mn[2];
+        int axis;
+        float pos;
+        if (dx > dy) {
+            if (dx > dz) { axis = 0; pos = 0.5f * dx + tb.mn[0]; }
+            else { axis = 2; pos = 0.5f * dz + tb.mn[2]; }
+        } else {
+            if (dy > dz) { axis = 1; pos = 0.5f * dy + tb.mn[1]; }
+            else { axis = 2; pos = 0.5f * dz + tb.mn[2]; }
+        }
+        Work& L = d.L;
+        Work& R = d.R;
+        L.box = tb; L.box.mx[axis] = pos;
+        R.box = tb; R.box.mn[axis] = pos;
+        {
+            std::vector<std::vector<Item>> partL((size_t)slices), partR((size_t)slices);
+            parallel_slices((size_t)n, slices, [&](int p, size_t b, size_t e) {
+                std::vector<Item>& Lp = partL[(size_t)p];
+                std::vector<Item>& Rp = partR[(size_t)p];
+                for (size_t i = b; i < e; i++) {
+                    const Item& it = w.items[i];
+                    bool toL = (it.mn[axis] < pos) || (it.mx[axis] <= pos);
+                    bool toR = (it.mx[axis] > pos) || (it.mn[axis] >= pos);
+                    if (toL && toR) {
+                        // straddler: clipped bounds in each child, never larger than before
+                        const float* v = verts + 9 * (size_t)it.tri;
+                        for (int side = 0; side < 2; side++) {
+                            const Box& cb = side == 0 ? L.box : R.box;
+                            Item c = it;
+                            float cmn[3], cmx[3];
+                            if (!clipped_bounds(v, cb, clip_pad, cmn, cmx)) continue;
+                            bool empty = false;
+                            for (int k = 0; k < 3; k++) {
+                                c.mn[k] = std::max(it.mn[k], std::max(cmn[k], cb.mn[k]));
+                                c.mx[k] = std::min(it.mx[k], std::min(cmx[k], cb.mx[k]));
+                                if (c.mn[k] > c.mx[k]) empty = true;
+                            }
+                            if (empty) continue;
+                            (side == 0 ? Lp : Rp).push_back(c);
+                        }
+                    } else if (toL) {
+                        Lp.push_back(it);
+                    } else {
+                        Rp.push_back(it);
+                    }
+                }
+            });
+            if (slices == 1) {
+                L.items.swap(partL[0]);
+                R.items.swap(partR[0]);
+            } else {
+                for (int p = 0; p < slices; p++) {      // slice order = triangle order
+                    L.items.insert(L.items.end(), partL[(size_t)p].begin(), partL[(size_t)p].end());
+                    R.items.insert(R.items.end(), partR[(size_t)p].begin(), partR[(size_t)p].end());
+                }
+            }
+        }
+        if (!((int)L.items.size() == n && (int)R.items.size() == n)) {
+            d.split = true;
+            d.axis = axis;
+            d.pos = pos;
+            L.small = R.small = false;
+            return;
+        }
+        // the median separates nothing: the node (after its cuts) goes through the SAH stage
+        L.items.clear();
+        R.items.clear();
+        w.box = tb;
+        w.small = true;
+    }
+
+    // ---------------- SAH stage ----------------
+    Box nb = w.box;
+    if (!w.small) {
+        // entering the stage: tighten the region to the triangles' boxes
+        for (int k = 0; k < 3; k++) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (const Item& it : w.items) { lo = std::min(lo, it.mn[k]); hi = std::max(hi, it.mx[k]); }
+            nb.mn[k] = std::max(nb.mn[k], lo);
+            nb.mx[k] = std::min(nb.mx[k], hi);
+        }
+    }
+    float area = box_area(nb.mn, nb.mx);
+    int best_axis = -1;
+    float best_pos = 0, best_cost = INFINITY;
+    if (area > 0 && depth < kMaxDepth) {
+        float inv_area = 1.f / area;
+        for (int a = 0; a < 3; a++) {
+            for (int side = 0; side < 2; side++) {
+                for (int j = 0; j < n; j++) {
+                    float pos = side == 0 ? w.items[(size_t)j].mn[a] : w.items[(size_t)j].mx[a];
+                    if (!(pos > nb.mn[a] && pos < nb.mx[a])) continue;
+                    int nl = 0, nr = 0;
+                    for (const Item& it : w.items) {
+                        nl += (it.mn[a] < pos) ? 1 : 0;
+                        nr += (it.mx[a] >= pos) ? 1 : 0;
+                    }
+                    if (nl == 0 || nr == 0) continue;
+                    float lmx[3] = {nb.mx[0], nb.mx[1], nb.mx[2]};
+                    float rmn[3] = {nb.mn[0], nb.mn[1], nb.mn[2]};
+                    lmx[a] = pos;
+                    rmn[a] = pos;
+                    float al = box_area(nb.mn, lmx);
+                    float ar = box_area(rmn, nb.mx);
+                    float cost = inv_area * ((float)nl * al + (float)nr * ar) + bp.traversal_cost;
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_pos = pos; }
+                }
+            }
+        }
+    }
+    if (best_axis < 0 || best_cost >= (float)n) return;     // leaf
+    d.split = true;
+    d.axis = best_axis;
+    d.pos = best_pos;
+    d.L.box = nb; d.L.box.mx[best_axis] = best_pos;
+    d.R.box = nb; d.R.box.mn[best_axis] = best_pos;
+    for (const Item& it : w.items) {
+        if (it.mn[best_axis] < best_pos) d.L.items.push_back(it);
+        if (it.mx[best_axis] >= best_pos) d.R.items.push_back(it);
+    }
+    d.L.small = d.R.small = true;
+}
+
+int build_threads() {
+    int t = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("GPT_BUILD_THREADS")) t = atoi(e);
+    return std::max(1, std::min(t, 16));
+}
+
+}  // namespace
+
 void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out) {
     out.nodes.clear();
     out.refs.clear();
@@ -134,8 +332,6 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out) {
     const double clip_pad = 1e-5 * (double)ext;
 
     out.nodes.push_back({0u, 0u});
-    std::deque<Work> queue;
-    queue.push_back(std::move(root));
 
     auto make_leaf = [&](uint32_t node, const std::vector<Item>& items, int depth) {
         out.nodes[node].w0 = ((uint32_t)out.refs.size() << 2) | 3u;
@@ -154,154 +350,57 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out) {
         return left;
     };
 
-    while (!queue.empty()) {
-        Work w = std::move(queue.front());
-        queue.pop_front();
-        const int n = (int)w.items.size();
-
-        if (n == 0) { make_leaf(w.node, w.items, w.depth); continue; }
-
-        if (!w.small && n > bp.small_threshold && w.depth < kMaxDepth - 8) {
-            // ---------------- large-node stage ----------------
-            Box tb;
-            for (int k = 0; k < 3; k++) { tb.mn[k] = INFINITY; tb.mx[k] = -INFINITY; }
-            for (const Item& it : w.items)
-                for (int k = 0; k < 3; k++) {
-                    tb.mn[k] = std::min(tb.mn[k], it.mn[k]);
-                    tb.mx[k] = std::max(tb.mx[k], it.mx[k]);
+    // Breadth-first, one tree level at a time: `level` holds the queue entries of the level in
+    // queue order.
+    const int n_threads = build_threads();
+    const std::vector<Item> no_items;
+    std::vector<Work> level, next;
+    level.push_back(std::move(root));
+    while (!level.empty()) {
+        std::vector<Decision> dec(level.size());
+        // ---- decide (parallel) ----
+        size_t total_items = 0;
+        for (const Work& w : level) total_items += w.items.size();
+        const int nt = total_items < 20000 ? 1 : (int)std::min<size_t>((size_t)n_threads, level.size());
+        if (nt < n_threads / 2 || nt <= 1) {
+            // few entries (the top of the tree, or a tiny tree): one after the other, threads inside
+            const int inner = total_items < 20000 ? 1 : n_threads;
+            for (size_t i = 0; i < level.size(); i++) decide(verts, bp, clip_pad, level[i], dec[i], inner);
+        } else {
+            std::atomic<size_t> next_entry(0);
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t i = next_entry.fetch_add(1);
+                    if (i >= level.size()) break;
+                    decide(verts, bp, clip_pad, level[i], dec[i], 1);
                 }
-            // empty-space cuts, thresholds from the incoming box
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+            worker();
+            for (std::thread& t : pool) t.join();
+        }
+        // ---- commit (queue order) ----
+        next.clear();
+        for (size_t i = 0; i < level.size(); i++) {
+            Work& w = level[i];
+            Decision& d = dec[i];
             uint32_t node = w.node;
             int depth = w.depth;
-            for (int a = 0; a < 3; a++) {
-                float thr = kEmptyRatio * (w.box.mx[a] - w.box.mn[a]);
-                if ((w.box.mx[a] - tb.mx[a]) - thr > 0) {          // cut above: right child empty
-                    uint32_t left = make_inner(node, a, tb.mx[a]);
-                    make_leaf(left + 1, std::vector<Item>(), depth + 1);
-                    node = left;
-                    depth++;
-                }
-                if ((tb.mn[a] - w.box.mn[a]) - thr > 0) {          // cut below: left child empty
-                    uint32_t left = make_inner(node, a, tb.mn[a]);
-                    make_leaf(left, std::vector<Item>(), depth + 1);
-                    node = left + 1;
-                    depth++;
-                }
+            for (int c = 0; c < d.n_cuts; c++) {
+                const uint32_t left = make_inner(node, d.cuts[c].axis, d.cuts[c].pos);
+                if (d.cuts[c].empty_right) { make_leaf(left + 1, no_items, depth + 1); node = left; }
+                else { make_leaf(left, no_items, depth + 1); node = left + 1; }
+                depth++;
             }
-            // spatial median of the tight box on its longest axis
-            float dx = tb.mx[0] - tb.mn[0], dy = tb.mx[1] - tb.mn[1], dz = tb.mx[2] - tb.mn[2];
-            int axis;
-            float pos;
-            if (dx > dy) {
-                if (dx > dz) { axis = 0; pos = 0.5f * dx + tb.mn[0]; }
-                else { axis = 2; pos = 0.5f * dz + tb.mn[2]; }
-            } else {
-                if (dy > dz) { axis = 1; pos = 0.5f * dy + tb.mn[1]; }
-                else { axis = 2; pos = 0.5f * dz + tb.mn[2]; }
-            }
-            Work L, R;
-            L.box = tb; L.box.mx[axis] = pos;
-            R.box = tb; R.box.mn[axis] = pos;
-            for (const Item& it : w.items) {
-                bool toL = (it.mn[axis] < pos) || (it.mx[axis] <= pos);
-                bool toR = (it.mx[axis] > pos) || (it.mn[axis] >= pos);
-                if (toL && toR) {
-                    // straddler: clipped bounds in each child, never larger than before
-                    const float* v = verts + 9 * (size_t)it.tri;
-                    for (int side = 0; side < 2; side++) {
-                        const Box& cb = side == 0 ? L.box : R.box;
-                        Item c = it;
-                        float cmn[3], cmx[3];
-                        if (!clipped_bounds(v, cb, clip_pad, cmn, cmx)) continue;
-                        bool empty = false;
-                        for (int k = 0; k < 3; k++) {
-                            c.mn[k] = std::max(it.mn[k], std::max(cmn[k], cb.mn[k]));
-                            c.mx[k] = std::min(it.mx[k], std::min(cmx[k], cb.mx[k]));
-                            if (c.mn[k] > c.mx[k]) empty = true;
-                        }
-                        if (empty) continue;
-                        (side == 0 ? L : R).items.push_back(c);
-                    }
-                } else if (toL) {
-                    L.items.push_back(it);
-                } else {
-                    R.items.push_back(it);
-                }
-            }
-            if ((int)L.items.size() == n && (int)R.items.size() == n) {
-                // the median separates nothing: hand the node to the SAH stage
-                w.node = node;
-                w.depth = depth;
-                w.box = tb;
-                w.small = true;
-                queue.push_front(std::move(w));
-                continue;
-            }
-            uint32_t left = make_inner(node, axis, pos);
-            L.node = left; R.node = left + 1;
-            L.depth = R.depth = depth + 1;
-            L.small = R.small = false;
-            queue.push_back(std::move(L));
-            queue.push_back(std::move(R));
-            continue;
+            if (!d.split) { make_leaf(node, w.items, depth); continue; }
+            const uint32_t left = make_inner(node, d.axis, d.pos);
+            d.L.node = left; d.R.node = left + 1;
+            d.L.depth = d.R.depth = depth + 1;
+            next.push_back(std::move(d.L));
+            next.push_back(std::move(d.R));
         }
-
-        // ---------------- SAH stage ----------------
-        Box nb = w.box;
-        if (!w.small) {
-            // entering the stage: tighten the region to the triangles' boxes
-            for (int k = 0; k < 3; k++) {
-                float lo = INFINITY, hi = -INFINITY;
-                for (const Item& it : w.items) { lo = std::min(lo, it.mn[k]); hi = std::max(hi, it.mx[k]); }
-                nb.mn[k] = std::max(nb.mn[k], lo);
-                nb.mx[k] = std::min(nb.mx[k], hi);
-            }
-        }
-        float area = box_area(nb.mn, nb.mx);
-        int best_axis = -1;
-        float best_pos = 0, best_cost = INFINITY;
-        if (area > 0 && w.depth < kMaxDepth) {
-            float inv_area = 1.f / area;
-            for (int a = 0; a < 3; a++) {
-                for (int side = 0; side < 2; side++) {
-                    for (int j = 0; j < n; j++) {
-                        float pos = side == 0 ? w.items[(size_t)j].mn[a] : w.items[(size_t)j].mx[a];
-                        if (!(pos > nb.mn[a] && pos < nb.mx[a])) continue;
-                        int nl = 0, nr = 0;
-                        for (const Item& it : w.items) {
-                            nl += (it.mn[a] < pos) ? 1 : 0;
-                            nr += (it.mx[a] >= pos) ? 1 : 0;
-                        }
-                        if (nl == 0 || nr == 0) continue;
-                        float lmx[3] = {nb.mx[0], nb.mx[1], nb.mx[2]};
-                        float rmn[3] = {nb.mn[0], nb.mn[1], nb.mn[2]};
-                        lmx[a] = pos;
-                        rmn[a] = pos;
-                        float al = box_area(nb.mn, lmx);
-                        float ar = box_area(rmn, nb.mx);
-                        float cost = inv_area * ((float)nl * al + (float)nr * ar) + bp.traversal_cost;
-                        if (cost < best_cost) { best_cost = cost; best_axis = a; best_pos = pos; }
-                    }
-                }
-            }
-        }
-        if (best_axis < 0 || best_cost >= (float)n) {
-            make_leaf(w.node, w.items, w.depth);
-            continue;
-        }
-        Work L, R;
-        L.box = nb; L.box.mx[best_axis] = best_pos;
-        R.box = nb; R.box.mn[best_axis] = best_pos;
-        for (const Item& it : w.items) {
-            if (it.mn[best_axis] < best_pos) L.items.push_back(it);
-            if (it.mx[best_axis] >= best_pos) R.items.push_back(it);
-        }
-        uint32_t left = make_inner(w.node, best_axis, best_pos);
-        L.node = left; R.node = left + 1;
-        L.depth = R.depth = w.depth + 1;
-        L.small = R.small = true;
-        queue.push_back(std::move(L));
-        queue.push_back(std::move(R));
+        level.swap(next);
     }
 }
 
