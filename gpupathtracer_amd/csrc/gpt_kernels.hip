@@ -182,9 +182,6 @@ struct DevStack {
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
         const int slot = sp & (KD_LDS_N - 1);
         if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
-#ifdef KD_SPILL_PROBE   // experiment: how many wave iterations execute this block
-            PT_COUNT_WAVE_ITERATION(1);
-#endif
 #pragma unroll
             for (int c = 0; c < 3; c++)
                 __builtin_nontemporal_store(lds[(3 * slot + c) * GPT_BLOCK], spill + (unsigned)(3 * lo + c) * spill_stride);
@@ -310,10 +307,6 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             unsigned refill_below, unsigned leaf_min) {
     __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
     __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
-#ifdef KD_LDS_PAD   // occupancy experiments: extra LDS per block
-    __shared__ uint32_t s_pad[KD_LDS_PAD / 4];
-    if (depth < 0) s_pad[threadIdx.x] = spill_stride, hit[0].x = s_pad[threadIdx.x ^ 1];
-#endif
     const unsigned n = counts[depth];
 
     KdCursor<DevStack, STATS> cur;
@@ -434,9 +427,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             const unsigned excl = incl - cnt;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             for (unsigned base = 0; base < total; base += 64) {
-#ifndef KD_SPILL_PROBE
                 if (STATS) PT_COUNT_WAVE_ITERATION(1);
-#endif
                 const unsigned p = base + lane;
                 // owner = last lane whose first pair number is <= p
                 unsigned L = 0;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME "<extra hipcc flags>" -> gpupathtracer_amd/lib/libgpt_hip_NAME.so
-# (an A/B build of the library with different kernel macros; select it with GPT_LIB_PATH)
+# (an A/B build of the library with different kernel macros, e.g. -DKD_WAVES_PER_EU=5 -DKD_LDS_N=16; select it with GPT_LIB_PATH)
 set -e
 cd "$(dirname "$0")/../gpupathtracer_amd/csrc"
 name=$1; shift
