@@ -295,7 +295,7 @@ void gpt_render_params_default(gpt_render_params* p) {
     p->row_stride_is_width = 1;
     p->use_kdtree = 1;
     p->kd_small_threshold = 64;
-    p->passes_in_flight = 8;
+    p->passes_in_flight = 0;
 }
 
 gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* polys, int numPolys,
@@ -311,7 +311,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     if (rp.max_depth < 0 || rp.max_depth > GPT_MAX_DEPTH)
         return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
     if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 64;
-    if (rp.passes_in_flight <= 0) rp.passes_in_flight = 1;
+    if (rp.passes_in_flight < 0) rp.passes_in_flight = 0;
     if (rp.passes_in_flight > 512) rp.passes_in_flight = 512;
 
     int ndev = 0;
@@ -462,6 +462,13 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
     if (numPixels != s->numPixels) {
         if ((st = free_pixel_buffers(s))) return st;
         int batch = s->params.passes_in_flight;
+        if (batch <= 0) {
+            // automatic: queues, hit slots and per-pass radiance take 128 bytes per pixel and pass
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t budget = free_b / 4;
+            batch = (int)std::max<size_t>(1, std::min<size_t>(256, budget / (128 * (size_t)numPixels)));
+        }
         while (batch > 1 && (long long)batch * numPixels > (1ll << 30)) batch--;
         if ((long long)numPixels > (1ll << 30)) return fail(GPT_ERR_TOO_LARGE, "too many pixels");
         const size_t n = (size_t)numPixels * (size_t)batch;
@@ -810,6 +817,7 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         gpt_render_params rp;
         if (L.params_set) rp = L.params;
         else { gpt_render_params_default(&rp); rp.row_stride_is_width = 0; }   // the reference's arithmetic
+        rp.passes_in_flight = 1;    // launchKernel traces one pass per call
         if (gpt_scene_create(hs.data(), numSpheres, hp.data(), numPolys, &rp, dev, &L.scene) != GPT_OK)
             die("launchKernel: scene upload failed:");
         L.polys = polys; L.spheres = spheres; L.numPolys = numPolys; L.numSpheres = numSpheres; L.checksum = sum;

@@ -164,8 +164,11 @@ typedef struct gpt_render_params {
     int    use_kdtree;
     int    kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64) */
     /* Passes traced together by gpt_render_range: every kernel launch covers the
-     * live paths of this many consecutive pass counters (default 8).  Results do
-     * not depend on it. */
+     * live paths of this many consecutive pass counters (at most 512).  Results
+     * do not depend on it; throughput does (every launch ends in a tail of its
+     * longest rays), and so does memory: 128 bytes per pixel and pass in flight.
+     * 0 (default): as many as fit in a quarter of the free device memory, up to
+     * 256. */
     int    passes_in_flight;
     int    reserved[6];
 } gpt_render_params;
