@@ -99,7 +99,7 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="cow_heavy")
     ap.add_argument("--subdiv", type=int, default=4)
