@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
     ap.add_argument("--batch", type=int, default=256, help="passes traced together per launch")
+    ap.add_argument("--kd-small", type=int, default=0, help="kd builder: node size at which the SAH stage takes over (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
@@ -140,7 +141,7 @@ def main():
     K, W = args.steps, args.warmup
 
     params = api.render_params(max_depth=args.depth, row_stride_is_width=1, use_kdtree=1,
-                               passes_in_flight=args.batch)
+                               passes_in_flight=args.batch, **({"kd_small_threshold": args.kd_small} if args.kd_small > 0 else {}))
     t_build = time.perf_counter()
     scene = api.Scene(spheres, polys, params, device=local_rank)
     t_build = time.perf_counter() - t_build

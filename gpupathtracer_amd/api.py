@@ -164,7 +164,7 @@ class Scene:
         return tri, t
 
 
-def kdtree_build(verts, small_threshold=64):
+def kdtree_build(verts, small_threshold=0):
     """Host kd-tree builder.  Returns dict(nodes[n,2] uint32, refs int32, bounds[6], max_depth)."""
     L = _lib.lib()
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)

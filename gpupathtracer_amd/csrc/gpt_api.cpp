@@ -294,7 +294,7 @@ void gpt_render_params_default(gpt_render_params* p) {
     p->ground_enabled = 1;
     p->row_stride_is_width = 1;
     p->use_kdtree = 1;
-    p->kd_small_threshold = 64;
+    p->kd_small_threshold = 24;
     p->passes_in_flight = 0;
 }
 
@@ -310,7 +310,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     if (params) rp = *params; else gpt_render_params_default(&rp);
     if (rp.max_depth < 0 || rp.max_depth > GPT_MAX_DEPTH)
         return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
-    if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 64;
+    if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 24;
     if (rp.passes_in_flight < 0) rp.passes_in_flight = 0;
     if (rp.passes_in_flight > 512) rp.passes_in_flight = 512;
 

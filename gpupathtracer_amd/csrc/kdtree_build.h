@@ -8,9 +8,12 @@ namespace gptkd {
 struct Node { uint32_t w0, w1; };
 
 struct BuildParams {
-    int   small_threshold = 64;   // <= this many triangles: SAH stage (cukd/kdtree.cu:76)
-    float traversal_cost = 1.0f;  // constant term of the SAH cost (cukd uses 6, small_node_array_kernels.cu:78-79;
-                                  // 1 measured fastest on MI355X: smaller leaves, fewer triangle tests)
+    // <= this many triangles: SAH stage (cukd/kdtree.cu:76 uses 64).  The pair (24, 3) measured
+    // fastest with the wave-cooperative traversal kernel on MI355X: a tree level costs a dependent
+    // memory access, a leaf triangle is tested 64 at a time -- so slightly larger leaves under
+    // median splits that reach further down.
+    int   small_threshold = 24;
+    float traversal_cost = 3.0f;  // constant term of the SAH cost (cukd uses 6, small_node_array_kernels.cu:78-79)
 };
 
 struct Tree {

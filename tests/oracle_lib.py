@@ -154,7 +154,7 @@ def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 
 
-def kd_build(verts, small_threshold=64, traversal_cost=1.0):
+def kd_build(verts, small_threshold=24, traversal_cost=3.0):
     """Oracle kd-tree builder (oracle/kdtree_oracle.c)."""
     L = lib()
     L.orc_kd_build.restype = ctypes.c_int

@@ -37,7 +37,7 @@ def mesh(name, levels=0):
 def test_layout_is_bit_exact_with_the_oracle_builder(name, levels):
     v = mesh(name, levels)
     a = api.kdtree_build(v)
-    b = O.kd_build(v, 64, 1.0)
+    b = O.kd_build(v, 24, 3.0)
     assert np.array_equal(a["nodes"], b["nodes"])
     assert np.array_equal(a["refs"], b["refs"])
     assert np.array_equal(a["bounds"], b["bounds"]) and a["max_depth"] == b["max_depth"]
@@ -52,7 +52,7 @@ def test_builder_is_deterministic_and_handles_degenerate_input():
     # 300 copies of one triangle cannot be separated: must terminate in a leaf
     tri = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (300, 1))
     t = api.kdtree_build(tri)
-    o = O.kd_build(tri, 64, 1.0)
+    o = O.kd_build(tri, 24, 3.0)
     assert np.array_equal(t["nodes"], o["nodes"]) and sorted(set(t["refs"])) == list(range(300))
     # zero-area triangles and a single point
     pts = np.zeros((100, 9), np.float32)
