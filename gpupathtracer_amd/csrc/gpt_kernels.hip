@@ -3,22 +3,25 @@
 // Wavefront formulation of the reference's launchKernel
 // (path_tracer_kernel.cu:760-882):
 //
-//   k_camera        raycastFromCameraKernel + initializeThings (:86-102,125-191)
+//   k_camera        raycastFromCameraKernel + initializeThings (:86-102,125-191),
+//                   and the new ray's closest ground / sphere hit (:509-533)
 //   per depth:
-//     k_intersect   closest hit of traceRayKernel (:495-557): ground, spheres,
-//                   then triangles by kd-tree traversal or by the reference's
-//                   brute-force loop
+//     k_intersect   the triangle part of traceRayKernel's closest hit
+//                   (:536-557), by kd-tree traversal or by the reference's
+//                   brute-force loop, starting from the ground / sphere hit
+//                   that arrived with the ray
 //     k_shade       the rest of traceRayKernel (:560-716) fused with the stream
 //                   compaction that replaces thrust::remove_if (:811-813): the
-//                   surviving paths are written, whole state, to the next
-//                   depth's queue at positions handed out by a wave64 ballot +
-//                   one atomic per wave
+//                   surviving paths are staged per block in LDS (wave64 ballot
+//                   + prefix counts) and written, whole state plus the new
+//                   ray's ground / sphere hit, to the next depth's queue, 512
+//                   slots per atomic
 //   k_finish        image += pass (PathTracer::render, path_tracer.cpp:100-103)
 //
 // Path state lives in compacted, structure-of-arrays queues (three 16-byte
-// words per path), double-buffered by depth parity; nothing returns to the host
-// between depths: the live count of depth d is a device counter that the
-// kernels of depth d read.
+// words and an 8-byte hit slot per path), double-buffered by depth parity;
+// nothing returns to the host between depths: the live count of depth d is a
+// device counter that the kernels of depth d read.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

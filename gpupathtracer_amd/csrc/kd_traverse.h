@@ -76,10 +76,11 @@ PT_HD int load_tri(const TriRec* tris, size_t slot, V3& a, V3& e1, V3& e2) {
 //                bool pop(uint32_t& node, float& tmin, float& tmax);
 //
 // KdCursor is a resumable traversal: begin() clips the ray against the root box,
-// advance() walks to the next leaf, tests its triangles and moves to the next
-// deferred interval; it returns true once nothing can beat the current best.
-// (The kernels interleave advance() calls of 64 rays per wave and hand finished
-// lanes new rays; the host harness simply loops.)
+// node_step() takes one inner node, next_interval() moves to the next deferred
+// interval.  advance() strings them together for one lane on its own (walk to the
+// next leaf, test its triangles, move on; true once nothing can beat the current
+// best): the host harness loops over it.  The GPU kernel calls the pieces itself,
+// because there the 64 lanes of a wave walk together and share the triangle tests.
 template <class Stack, bool STATS>
 struct KdCursor {
     V3 o, d, inv;
