@@ -490,10 +490,15 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 // staging area, and whenever 512 have gathered the block reserves 512 queue
 // slots with ONE atomic and writes them out as full coalesced rows.
 // ---------------------------------------------------------------------------
+#ifndef SHADE_FLUSH
 #define SHADE_FLUSH 512
+#endif
+#ifndef SHADE_WAVES_PER_EU
+#define SHADE_WAVES_PER_EU 4
+#endif
 #define SHADE_STAGE (SHADE_FLUSH + GPT_BLOCK)
 
-__global__ __launch_bounds__(GPT_BLOCK) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
+__global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
                                                      int numPasses,
                                                      const float4* __restrict__ in_o,
                                                      const float4* __restrict__ in_d,
