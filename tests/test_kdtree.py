@@ -43,6 +43,19 @@ def test_layout_is_bit_exact_with_the_oracle_builder(name, levels):
     assert np.array_equal(a["bounds"], b["bounds"]) and a["max_depth"] == b["max_depth"]
 
 
+def test_tree_does_not_depend_on_the_builder_thread_count(monkeypatch):
+    """Worker threads decide, numbering happens in queue order: 1, 3 and 16 threads give one tree
+    (large enough that both the per-level workers and the slices inside huge entries are used)."""
+    v = mesh("cow", 3)                      # 371 456 triangles
+    trees = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("GPT_BUILD_THREADS", threads)
+        trees.append(api.kdtree_build(v))
+    for t in trees[1:]:
+        assert np.array_equal(t["nodes"], trees[0]["nodes"]) and np.array_equal(t["refs"], trees[0]["refs"])
+    assert trees[0]["nodes"].shape[0] > 100000
+
+
 def test_builder_is_deterministic_and_handles_degenerate_input():
     v, _ = meshes.random_soup(5000, seed=1)
     a, b = api.kdtree_build(v), api.kdtree_build(v)
