@@ -56,6 +56,18 @@ PT_HD float bits_to_float(uint32_t u) {
 #endif
 }
 
+// Reciprocal for the traversal's interval arithmetic.  Which nodes are visited only has to be
+// conservative, not reproducible to the bit: the hardware reciprocal (1 ulp, one instruction
+// instead of the ten of an IEEE division) changes a plane distance by ~1e-7 relative, far inside
+// the 4e-6 relative slack every interval decision carries.  x = 0 gives +-inf on both sides.
+PT_HD float kd_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 PT_HD int float_to_int_bits(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __float_as_int(f);
@@ -99,13 +111,15 @@ struct KdCursor {
         bestTri = -1;
         tmin = 0.0f;
         tmax = t_limit;
+        inv = v3(kd_rcp(d.x), kd_rcp(d.y), kd_rcp(d.z));
         const float oc[3] = {o.x, o.y, o.z};
         const float dc[3] = {d.x, d.y, d.z};
+        const float ic[3] = {inv.x, inv.y, inv.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
             if (dc[a] != 0.0f) {
-                float iv = 1.0f / dc[a];
+                float iv = ic[a];
                 float ta = (lo - oc[a]) * iv, tb = (hi - oc[a]) * iv;
                 float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
                 tn -= PT_KD_REL_SLACK * fabsf(tn);
@@ -117,7 +131,6 @@ struct KdCursor {
             }
         }
         if (!(tmin <= tmax)) return false;
-        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         node = 0;
         st.reset();
         return true;
