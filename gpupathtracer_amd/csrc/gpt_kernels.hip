@@ -291,6 +291,31 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int tri) {
     return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)(tri + 1);
 }
 
+// Inclusive wave64 scans in registers (DPP row shifts, then the two row broadcasts; every lane
+// of the wave must be active).  Lanes without a source take the identity 0.
+#define GPT_DPP_STEP(op, v, ctrl, row_mask) \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, row_mask, 0xf, false))
+__device__ __forceinline__ unsigned dpp_add(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned dpp_max(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+    GPT_DPP_STEP(dpp_add, v, 0x111, 0xf);   // row_shr:1
+    GPT_DPP_STEP(dpp_add, v, 0x112, 0xf);   // row_shr:2
+    GPT_DPP_STEP(dpp_add, v, 0x114, 0xf);   // row_shr:4
+    GPT_DPP_STEP(dpp_add, v, 0x118, 0xf);   // row_shr:8
+    GPT_DPP_STEP(dpp_add, v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    GPT_DPP_STEP(dpp_add, v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ unsigned wave_inclusive_max(unsigned v) {
+    GPT_DPP_STEP(dpp_max, v, 0x111, 0xf);
+    GPT_DPP_STEP(dpp_max, v, 0x112, 0xf);
+    GPT_DPP_STEP(dpp_max, v, 0x114, 0xf);
+    GPT_DPP_STEP(dpp_max, v, 0x118, 0xf);
+    GPT_DPP_STEP(dpp_max, v, 0x142, 0xa);
+    GPT_DPP_STEP(dpp_max, v, 0x143, 0xc);
+    return v;
+}
+
 __device__ __forceinline__ int bperm(unsigned byte_addr, int v) {
     return __builtin_amdgcn_ds_bpermute((int)byte_addr, v);
 }
@@ -310,6 +335,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             unsigned refill_below, unsigned leaf_min) {
     __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
     __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
+    __shared__ unsigned char s_owner[GPT_BLOCK];       // per wave: 64 marks of the test phase's owner search
     const unsigned n = counts[depth];
 
     KdCursor<DevStack, STATS> cur;
@@ -421,25 +447,23 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
         // ---- test ----
         {
             const unsigned cnt = parked ? leafCount : 0u;
-            unsigned incl = cnt;
-#pragma unroll
-            for (unsigned off = 1; off < 64; off <<= 1) {
-                const unsigned v = (unsigned)bperm((lane - off) << 2, (int)incl);
-                if (lane >= off) incl += v;
-            }
+            const unsigned incl = wave_inclusive_sum(cnt);
             const unsigned excl = incl - cnt;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             for (unsigned base = 0; base < total; base += 64) {
                 if (STATS) PT_COUNT_WAVE_ITERATION(1);
                 const unsigned p = base + lane;
-                // owner = last lane whose first pair number is <= p
-                unsigned L = 0;
-#pragma unroll
-                for (unsigned s = 32; s > 0; s >>= 1) {
-                    const unsigned c = L + s;
-                    const unsigned e = (unsigned)bperm(c << 2, (int)excl);
-                    if (e <= p) L = c;
-                }
+                // owner of pair p = last lane with triangles whose first pair number is <= p: the lanes
+                // whose run starts inside this chunk mark the start in a 64-byte LDS row, a running
+                // maximum spreads the marks, and the run reaching in from the previous chunk belongs to
+                // the last lane that starts at or before `base`
+                s_owner[threadIdx.x] = 0;
+                if (cnt != 0u && excl >= base && excl - base < 64u) s_owner[wave_base + (excl - base)] = (unsigned char)lane;
+                __builtin_amdgcn_wave_barrier();
+                const unsigned mark = s_owner[threadIdx.x];
+                const unsigned long long before = __ballot(cnt != 0u && excl <= base);
+                const unsigned carry = 63u - (unsigned)__builtin_clzll(before);
+                const unsigned L = dpp_max(wave_inclusive_max(mark), carry);
                 const unsigned la = L << 2;
                 const unsigned k = p - (unsigned)bperm(la, (int)excl);
                 const unsigned first = (unsigned)bperm(la, (int)leafFirst);
