@@ -183,7 +183,7 @@ struct DevStack {
     // flat accesses.
     __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
-        const int slot = sp & (KD_LDS_N - 1);
+        const int slot = (int)((unsigned)sp % KD_LDS_N);
         if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
 #pragma unroll
             for (int c = 0; c < 3; c++)
@@ -201,7 +201,7 @@ struct DevStack {
         // the LDS slot is read unconditionally (it is always a valid address) and overridden in the
         // rare spilled case; otherwise the compiler selects between the two ADDRESSES and emits
         // generic flat loads
-        const int slot = sp & (KD_LDS_N - 1);
+        const int slot = (int)((unsigned)sp % KD_LDS_N);
         node = lds[(3 * slot + 0) * GPT_BLOCK];
         tmin = __uint_as_float(lds[(3 * slot + 1) * GPT_BLOCK]);
         tmax = __uint_as_float(lds[(3 * slot + 2) * GPT_BLOCK]);
