@@ -465,12 +465,11 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned carry = 63u - (unsigned)__builtin_clzll(before);
                 const unsigned L = dpp_max(wave_inclusive_max(mark), carry);
                 const unsigned la = L << 2;
-                const unsigned k = p - (unsigned)bperm(la, (int)excl);
-                const unsigned first = (unsigned)bperm(la, (int)leafFirst);
+                const unsigned rec0 = p + (unsigned)bperm(la, (int)(leafFirst - excl));   // owner's first record + (p - owner's first pair)
                 const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
                 const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
                 if (p < total) {
-                    const size_t rec = g.kd.refs ? (size_t)g.kd.refs[first + k] : (size_t)first + k;
+                    const size_t rec = g.kd.refs ? (size_t)g.kd.refs[rec0] : (size_t)rec0;
                     // the whole record at once (left alone, the compiler fetches `a` only after the
                     // determinant test: a second memory latency in every chunk)
                     const float4* rp = reinterpret_cast<const float4*>(g.kd.leaf_tris + rec);
