@@ -374,6 +374,9 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         std::vector<int32_t> dev_refs;
         if (getenv("GPT_NO_DFS_LEAVES")) dev_refs = tree.refs;
         else gptkd::leaf_order_refs(dev_nodes, tree.refs, dev_refs);
+        // device copy only: inner nodes learn which of their children are empty leaves
+        if (dev_nodes.size() > (size_t)PT_KD_CHILD_MASK) { st = fail(GPT_ERR_TOO_LARGE, "kd-tree has too many nodes"); break; }
+        pt::kd_mark_empty_children(reinterpret_cast<pt::KdNode*>(dev_nodes.data()), dev_nodes.size());
         // Leaf triangles: records duplicated in leaf order (a leaf visit then costs ONE memory
         // latency: the kernel is bound by dependent loads, not by footprint); only a copy beyond
         // 16 GiB falls back to an index list into the per-triangle records.

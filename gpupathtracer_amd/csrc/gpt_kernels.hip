@@ -433,7 +433,10 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
                 const KdNode w = g.kd.nodes[cur.node];
                 if ((w.w0 & 3u) != 3u) {
-                    cur.node_step(g.kd, w);
+                    if (cur.node_step(g.kd, w)) {   // only empty leaves below: same as standing in one
+                        leafCount = 0;
+                        parked = true;
+                    }
                 } else {
                     leafFirst = w.w0 >> 2;
                     leafCount = w.w1;     // may be 0: an empty leaf

@@ -38,6 +38,20 @@ struct KdView {
 };
 
 #define PT_KD_REL_SLACK 4e-6f
+#define PT_KD_CHILD_MASK 0x0fffffffu   // child index field of an inner node's w0 (above the 2 axis bits)
+
+// Sets bits 30 / 31 in the w0 of every inner node whose left / right child is an empty leaf
+// (what the device copy of a tree gets; see KdCursor::node_step).  Node indices must fit 28 bits.
+inline void kd_mark_empty_children(KdNode* nodes, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if ((nodes[i].w0 & 3u) == 3u) continue;
+        const uint32_t left = (nodes[i].w0 >> 2) & PT_KD_CHILD_MASK;
+        const KdNode& l = nodes[left];
+        const KdNode& r = nodes[left + 1];
+        if ((l.w0 & 3u) == 3u && l.w1 == 0u) nodes[i].w0 |= 1u << 30;
+        if ((r.w0 & 3u) == 3u && r.w1 == 0u) nodes[i].w0 |= 1u << 31;
+    }
+}
 
 // Instrumented builds only: counts how many times a WAVE executes the body of the node loop
 // (slot 0) and of the triangle loop (slot 1), to relate them to the lanes' own counts
@@ -147,10 +161,16 @@ struct KdCursor {
 
     // One inner node `w`: chooses the child to enter (into `node`), defers the other one with
     // its interval when the ray can reach it, and trims [tmin, tmax].
-    PT_HD void node_step(const KdView& kd, KdNode w) {
+    // Bits 30 / 31 of an inner node's w0 say that its left / right child is an EMPTY leaf
+    // (kd_mark_empty_children; the builder's own output has them clear, and 28 bits of child
+    // index).  Such a child is never entered or deferred: no load, no stack traffic.  Returns
+    // true when that leaves nothing to visit under this node (the caller moves on to the next
+    // deferred interval, exactly as it would from an empty leaf).
+    PT_HD bool node_step(const KdView& kd, KdNode w) {
         const int axis = (int)(w.w0 & 3u);
         const float split = bits_to_float(w.w1);
-        const uint32_t left = w.w0 >> 2;
+        const uint32_t left = (w.w0 >> 2) & PT_KD_CHILD_MASK;
+        const bool emptyL = ((w.w0 >> 30) & 1u) != 0u, emptyR = (w.w0 >> 31) != 0u;
         const float oa = sel3(axis, o.x, o.y, o.z);
         const float da = sel3(axis, d.x, d.y, d.z);
         const float ia = sel3(axis, inv.x, inv.y, inv.z);
@@ -159,6 +179,8 @@ struct KdCursor {
         const bool leftFirst = (oa < split) | ((oa == split) & (da <= 0.0f));
         const uint32_t nearC = leftFirst ? left : left + 1u;
         const uint32_t farC = leftFirst ? left + 1u : left;
+        const bool nearEmpty = leftFirst ? emptyL : emptyR;
+        const bool farEmpty = leftFirst ? emptyR : emptyL;
         // Four outcomes:
         //   near only   plane beyond the interval, or behind the origin, or ray parallel
         //               to it and outside the thickened plane
@@ -177,11 +199,16 @@ struct KdCursor {
         const bool bothWhole = (parallel & inSlab) | (crossing & behind);
         const bool farOnly = crossing & !behind & before;
         const bool bothCut = crossing & !behind & !before;
+        const bool both = bothWhole | bothCut;
         // (tmin and tmax are never NaN; a NaN lo / hi compares false and leaves them as they are,
         // which is what fmaxf / fminf would do, at half the instructions)
-        if (bothWhole | bothCut) st.push(farC, (bothCut & (lo > tmin)) ? lo : tmin, tmax);
-        node = farOnly ? farC : nearC;
-        tmax = (bothCut & (hi < tmax)) ? hi : tmax;
+        const float farTmin = (bothCut & (lo > tmin)) ? lo : tmin;
+        if (both & !nearEmpty & !farEmpty) st.push(farC, farTmin, tmax);
+        const bool takeFar = farOnly | (both & nearEmpty);
+        node = takeFar ? farC : nearC;
+        tmin = (both & nearEmpty) ? farTmin : tmin;
+        tmax = (bothCut & !nearEmpty & (hi < tmax)) ? hi : tmax;
+        return takeFar ? farEmpty : nearEmpty;
     }
 
     // One leaf visit.  Returns true when the traversal is complete.
@@ -190,7 +217,7 @@ struct KdCursor {
         if (STATS) nodesVisited++;
         while ((w.w0 & 3u) != 3u) {
             if (STATS) PT_COUNT_WAVE_ITERATION(0);
-            node_step(kd, w);
+            if (node_step(kd, w)) return !next_interval();
             w = kd.nodes[node];
             if (STATS) nodesVisited++;
         }
