@@ -364,6 +364,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         gptkd::BuildParams bp;
         bp.small_threshold = rp.kd_small_threshold;
         if (const char* e = getenv("GPT_KD_COST")) bp.traversal_cost = (float)atof(e);
+        if (const char* e = getenv("GPT_KD_EMPTY_RATIO")) bp.empty_ratio = (float)atof(e);
         gptkd::build(verts.data(), numPolys, bp, tree);
         s->n_refs = (int)tree.refs.size();
         s->tree_depth = tree.max_depth;

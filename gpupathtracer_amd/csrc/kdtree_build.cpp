@@ -53,7 +53,6 @@ struct Work {
 };
 
 const int kMaxDepth = 56;
-const float kEmptyRatio = 0.12f;
 
 inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
@@ -163,7 +162,7 @@ void decide(const float* verts, const BuildParams& bp, double clip_pad, Work& w,
         }
         // empty-space cuts, thresholds from the incoming box
         for (int a = 0; a < 3; a++) {
-            float thr = kEmptyRatio * (w.box.mx[a] - w.box.mn[a]);
+            float thr = bp.empty_ratio * (w.box.mx[a] - w.box.mn[a]);
             if ((w.box.mx[a] - tb.mx[a]) - thr > 0) { d.cuts[d.n_cuts++] = {a, tb.mx[a], true}; depth++; }   // right child empty
             if ((tb.mn[a] - w.box.mn[a]) - thr > 0) { d.cuts[d.n_cuts++] = {a, tb.mn[a], false}; depth++; }  // left child empty
         }

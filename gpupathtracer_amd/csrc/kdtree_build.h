@@ -13,6 +13,7 @@ struct BuildParams {
     // memory access, a leaf triangle is tested 64 at a time -- so slightly larger leaves under
     // median splits that reach further down.
     int   small_threshold = 24;
+    float empty_ratio = 0.12f;    // large nodes: an empty margin wider than this share of the node extent is cut off
     float traversal_cost = 3.0f;  // constant term of the SAH cost (cukd uses 6, small_node_array_kernels.cu:78-79)
 };
 
