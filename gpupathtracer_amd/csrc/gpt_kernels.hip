@@ -158,7 +158,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 
 // ---------------------------------------------------------------------------
 // Traversal stack: the top KD_LDS_N entries of every lane live in LDS
-// ([entry][thread] so a wave's accesses never conflict), older entries spill to
+// ([word][thread] so a wave's accesses never conflict), older entries spill to
 // a per-thread column of a global buffer and come back when the LDS part runs
 // empty.  Depth never exceeds the tree's depth, which sizes the spill buffer.
 // ---------------------------------------------------------------------------
@@ -169,11 +169,16 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 #define KD_FETCH_CHUNK 512u   // rays a wave takes from the global queue per atomic
 #endif
 #ifndef KD_WAVES_PER_EU
-#define KD_WAVES_PER_EU 6
+#define KD_WAVES_PER_EU 7
 #endif
 
 struct DevStack {
-    uint32_t* lds;          // this thread's column: lds[(3*e + c) * GPT_BLOCK]
+    // An entry is 10 bytes: node, tmin, and the interval LENGTH tmax - tmin rounded UP to its upper
+    // 16 float bits.  The stored interval always contains the exact one (traversal stays
+    // conservative), and being off by < 1 % of its own length it costs next to nothing -- rounding
+    // tmax itself would misplace the end by 1 % of the DISTANCE, many leaves' worth far from the origin.
+    uint32_t* lds;          // this thread's column of words:     lds[(2*e + c) * GPT_BLOCK], c = 0 node, 1 tmin
+    uint16_t* lds16;        // this thread's column of halfwords: lds16[e * GPT_BLOCK]
     uint32_t* spill;        // this thread's column: spill[(3*e + c) * spill_stride]
     unsigned spill_stride;  // (3 * depth * stride fits 32 bits: checked by the host)
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
@@ -185,14 +190,14 @@ struct DevStack {
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
         const int slot = (int)((unsigned)sp % KD_LDS_N);
         if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                __builtin_nontemporal_store(lds[(3 * slot + c) * GPT_BLOCK], spill + (unsigned)(3 * lo + c) * spill_stride);
+            __builtin_nontemporal_store(lds[(2 * slot + 0) * GPT_BLOCK], spill + (unsigned)(3 * lo + 0) * spill_stride);
+            __builtin_nontemporal_store(lds[(2 * slot + 1) * GPT_BLOCK], spill + (unsigned)(3 * lo + 1) * spill_stride);
+            __builtin_nontemporal_store((uint32_t)lds16[slot * GPT_BLOCK], spill + (unsigned)(3 * lo + 2) * spill_stride);
             lo++;
         }
-        lds[(3 * slot + 0) * GPT_BLOCK] = node;
-        lds[(3 * slot + 1) * GPT_BLOCK] = __float_as_uint(tmin);
-        lds[(3 * slot + 2) * GPT_BLOCK] = __float_as_uint(tmax);
+        lds[(2 * slot + 0) * GPT_BLOCK] = node;
+        lds[(2 * slot + 1) * GPT_BLOCK] = __float_as_uint(tmin);
+        lds16[slot * GPT_BLOCK] = (uint16_t)((__float_as_uint(fmaxf(tmax - tmin, 0.0f)) + 0xffffu) >> 16);
         sp++;
     }
     __device__ __forceinline__ bool pop(uint32_t& node, float& tmin, float& tmax) {
@@ -202,17 +207,19 @@ struct DevStack {
         // rare spilled case; otherwise the compiler selects between the two ADDRESSES and emits
         // generic flat loads
         const int slot = (int)((unsigned)sp % KD_LDS_N);
-        node = lds[(3 * slot + 0) * GPT_BLOCK];
-        tmin = __uint_as_float(lds[(3 * slot + 1) * GPT_BLOCK]);
-        tmax = __uint_as_float(lds[(3 * slot + 2) * GPT_BLOCK]);
-        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // the values, not the addresses, meet below
+        node = lds[(2 * slot + 0) * GPT_BLOCK];
+        tmin = __uint_as_float(lds[(2 * slot + 1) * GPT_BLOCK]);
+        uint32_t len = lds16[slot * GPT_BLOCK];
+        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));   // the values, not the addresses, meet below
         if (sp < lo) {
             node = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 0) * spill_stride);
             tmin = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 1) * spill_stride));
-            tmax = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride));
-            asm volatile("" : "+v"(node), "+v"(tmin), "+v"(tmax));   // wait here, in the rare branch, not at a later join
+            len = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride);
+            asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));   // wait here, in the rare branch, not at a later join
             lo = sp;
         }
+        // (the product covers the rounding of the subtraction above and of this addition)
+        tmax = (tmin + __uint_as_float(len << 16)) * 1.000001f;
         return true;
     }
 };
@@ -333,13 +340,15 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             unsigned long long* __restrict__ stats,
                                                             uint32_t* __restrict__ spill, size_t spill_stride,
                                                             unsigned refill_below, unsigned leaf_min) {
-    __shared__ uint32_t s_stack[3 * KD_LDS_N * GPT_BLOCK];
+    __shared__ uint32_t s_stack[2 * KD_LDS_N * GPT_BLOCK];
+    __shared__ uint16_t s_stack_len[KD_LDS_N * GPT_BLOCK];
     __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
     __shared__ unsigned char s_owner[GPT_BLOCK];       // per wave: 64 marks of the test phase's owner search
     const unsigned n = counts[depth];
 
     KdCursor<DevStack, STATS> cur;
     cur.st.lds = s_stack + threadIdx.x;
+    cur.st.lds16 = s_stack_len + threadIdx.x;
     cur.st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
     cur.st.spill_stride = (unsigned)spill_stride;
     cur.st.reset();
