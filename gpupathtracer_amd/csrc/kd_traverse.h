@@ -170,17 +170,19 @@ struct KdCursor {
         const int axis = (int)(w.w0 & 3u);
         const float split = bits_to_float(w.w1);
         const uint32_t left = (w.w0 >> 2) & PT_KD_CHILD_MASK;
-        const bool emptyL = ((w.w0 >> 30) & 1u) != 0u, emptyR = (w.w0 >> 31) != 0u;
+        const bool emptyL = (w.w0 & 0x40000000u) != 0u, emptyR = (int32_t)w.w0 < 0;
         const float oa = sel3(axis, o.x, o.y, o.z);
-        const float da = sel3(axis, d.x, d.y, d.z);
+        // the direction enters through its reciprocal only: +-inf stands for a ray parallel to the plane
         const float ia = sel3(axis, inv.x, inv.y, inv.z);
         // (plain '&' and '|' on purpose: every term is cheap and a short-circuit would only
         // add branches that the lanes of a wave take differently)
-        const bool leftFirst = (oa < split) | ((oa == split) & (da <= 0.0f));
+        // On the plane exactly, the side the ray leaves towards comes first (a parallel ray there
+        // visits both children with the whole interval, in either order).
+        const bool leftFirst = (oa < split) | ((oa == split) & (ia < 0.0f));
         const uint32_t nearC = leftFirst ? left : left + 1u;
         const uint32_t farC = leftFirst ? left + 1u : left;
-        const bool nearEmpty = leftFirst ? emptyL : emptyR;
-        const bool farEmpty = leftFirst ? emptyR : emptyL;
+        const bool nearEmpty = (leftFirst & emptyL) | (!leftFirst & emptyR);
+        const bool farEmpty = (leftFirst & emptyR) | (!leftFirst & emptyL);
         // Four outcomes:
         //   near only   plane beyond the interval, or behind the origin, or ray parallel
         //               to it and outside the thickened plane
@@ -188,7 +190,7 @@ struct KdCursor {
         //               be real or lie behind the origin), or parallel inside it
         //   far only    plane crossed before the interval starts
         //   both, cut   near gets [tmin, min(tmax,hi)], far gets [max(tmin,lo), tmax]
-        const bool parallel = (da == 0.0f);
+        const bool parallel = fabsf(ia) == INFINITY;
         const bool inSlab = fabsf(oa - split) <= kd.sigma;
         const float tp = (split - oa) * ia;
         const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
@@ -208,7 +210,7 @@ struct KdCursor {
         node = takeFar ? farC : nearC;
         tmin = (both & nearEmpty) ? farTmin : tmin;
         tmax = (bothCut & !nearEmpty & (hi < tmax)) ? hi : tmax;
-        return takeFar ? farEmpty : nearEmpty;
+        return (takeFar & farEmpty) | (!takeFar & nearEmpty);
     }
 
     // One leaf visit.  Returns true when the traversal is complete.
