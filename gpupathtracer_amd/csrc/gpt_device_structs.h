@@ -23,8 +23,8 @@
 #define GPT_STAT_HITS (GPT_MAX_DEPTH + 2)     // closest-hit queries that found something
 #define GPT_STAT_WAVE_ITERS_NODE (GPT_MAX_DEPTH + 3)   // wave executions of the node-loop body
 #define GPT_STAT_WAVE_ITERS_TRI (GPT_MAX_DEPTH + 4)    // wave executions of the triangle-loop body
-#define GPT_STAT_BUSY_LANE_ROUNDS (GPT_MAX_DEPTH + 5)  // lane-level advance() calls
-#define GPT_STAT_WAVE_ROUNDS (GPT_MAX_DEPTH + 6)       // wave-level advance() rounds
+#define GPT_STAT_BUSY_LANE_ROUNDS (GPT_MAX_DEPTH + 5)  // walk iterations summed over the lanes holding a ray
+#define GPT_STAT_WAVE_ROUNDS (GPT_MAX_DEPTH + 6)       // walk iterations of the waves
 #define GPT_STAT_NODES_D0 (GPT_MAX_DEPTH + 8)          // [GPT_MAX_DEPTH] kd nodes visited per depth
 #define GPT_STAT_TRIS_D0 (2 * GPT_MAX_DEPTH + 8)       // [GPT_MAX_DEPTH] triangles tested per depth
 #define GPT_STAT_WORDS (3 * GPT_MAX_DEPTH + 8)

@@ -231,8 +231,10 @@ typedef struct gpt_stats {
     uint64_t trace_launches;
     uint64_t kd_nodes_at_depth[64];   /* instrumented build only */
     uint64_t kd_tris_at_depth[64];
-    /* SIMD utilisation of the traversal loops (instrumented build only): how often a wave
-     * executed the node-loop / triangle-loop body, and lane- vs wave-level leaf rounds. */
+    /* SIMD utilisation of the traversal kernel (instrumented build only): how often a wave
+     * executed a walk iteration (one tree level for every walking lane) / a 64-pair chunk of
+     * the triangle phase -- divide kd_nodes_visited / kd_tris_tested by them for lanes per
+     * iteration -- and the walk iterations summed over lanes holding a ray vs over waves. */
     uint64_t wave_iters_node, wave_iters_tri, busy_lane_rounds, wave_rounds;
 } gpt_stats;
 gpt_status gpt_get_stats(gpt_scene* scene, gpt_stats* out);

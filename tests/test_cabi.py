@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_pod_layouts_match_the_reference_structs():
-    # sizes from SURVEY of the CUDA layouts: Camera 64 (float2 8-aligned), Sphere 76, Poly 120, ...
+    # sizes of the CUDA layouts (nvcc alignment rules): Camera 64 (float2 8-aligned), Sphere 76, Poly 120, ...
     assert AS_DTYPE.itemsize == 16 and MEDIUM_DTYPE.itemsize == 20 and MATERIAL_DTYPE.itemsize == 60
     assert SPHERE_DTYPE.itemsize == 76 and POLY_DTYPE.itemsize == 120 and RAY_DTYPE.itemsize == 24
     assert CAMERA_DTYPE.itemsize == 64 and CAMERA_DTYPE.fields["fov"][1] == 48
