@@ -170,7 +170,7 @@ struct KdCursor {
         const int axis = (int)(w.w0 & 3u);
         const float split = bits_to_float(w.w1);
         const uint32_t left = (w.w0 >> 2) & PT_KD_CHILD_MASK;
-        const bool emptyL = (w.w0 & 0x40000000u) != 0u, emptyR = (int32_t)w.w0 < 0;
+        const bool emptyL = (int32_t)(w.w0 << 1) < 0, emptyR = (int32_t)w.w0 < 0;
         const float oa = sel3(axis, o.x, o.y, o.z);
         // the direction enters through its reciprocal only: +-inf stands for a ray parallel to the plane
         const float ia = sel3(axis, inv.x, inv.y, inv.z);
@@ -181,8 +181,8 @@ struct KdCursor {
         const bool leftFirst = (oa < split) | ((oa == split) & (ia < 0.0f));
         const uint32_t nearC = leftFirst ? left : left + 1u;
         const uint32_t farC = leftFirst ? left + 1u : left;
-        const bool nearEmpty = (leftFirst & emptyL) | (!leftFirst & emptyR);
-        const bool farEmpty = (leftFirst & emptyR) | (!leftFirst & emptyL);
+        const bool nearEmpty = leftFirst ? emptyL : emptyR;
+        const bool farEmpty = leftFirst ? emptyR : emptyL;
         // Four outcomes:
         //   near only   plane beyond the interval, or behind the origin, or ray parallel
         //               to it and outside the thickened plane
@@ -210,7 +210,7 @@ struct KdCursor {
         node = takeFar ? farC : nearC;
         tmin = (both & nearEmpty) ? farTmin : tmin;
         tmax = (bothCut & !nearEmpty & (hi < tmax)) ? hi : tmax;
-        return (takeFar & farEmpty) | (!takeFar & nearEmpty);
+        return takeFar ? farEmpty : nearEmpty;
     }
 
     // One leaf visit.  Returns true when the traversal is complete.
