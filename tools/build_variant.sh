@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../gpupathtracer_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
-FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -Wno-unused-value $*"
+FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-result -Wno-unused-value $*"
 /opt/rocm/bin/hipcc $FLAGS -c -o $tmp/k.o gpt_kernels.hip
 for f in gpt_api gpt_host_io kdtree_build; do /opt/rocm/bin/hipcc $FLAGS -x hip -c -o $tmp/$f.o $f.cpp & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpt_hip_$name.so $tmp/*.o
