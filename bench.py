@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
-    ap.add_argument("--batch", type=int, default=256, help="passes traced together per launch")
+    ap.add_argument("--batch", type=int, default=512, help="passes traced together per launch")
     ap.add_argument("--kd-small", type=int, default=0, help="kd builder: node size at which the SAH stage takes over (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")

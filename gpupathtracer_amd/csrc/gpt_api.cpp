@@ -470,8 +470,8 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
             // automatic: queues, hit slots and per-pass radiance take 128 bytes per pixel and pass
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t budget = free_b / 4;
-            batch = (int)std::max<size_t>(1, std::min<size_t>(256, budget / (128 * (size_t)numPixels)));
+            const size_t budget = free_b / 2;
+            batch = (int)std::max<size_t>(1, std::min<size_t>(512, budget / (128 * (size_t)numPixels)));
         }
         while (batch > 1 && (long long)batch * numPixels > (1ll << 30)) batch--;
         if ((long long)numPixels > (1ll << 30)) return fail(GPT_ERR_TOO_LARGE, "too many pixels");

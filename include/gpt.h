@@ -167,8 +167,8 @@ typedef struct gpt_render_params {
      * live paths of this many consecutive pass counters (at most 512).  Results
      * do not depend on it; throughput does (every launch ends in a tail of its
      * longest rays), and so does memory: 128 bytes per pixel and pass in flight.
-     * 0 (default): as many as fit in a quarter of the free device memory, up to
-     * 256. */
+     * 0 (default): as many as fit in half of the free device memory, up to
+     * 512. */
     int    passes_in_flight;
     int    reserved[6];
 } gpt_render_params;
