@@ -357,11 +357,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 
     uint32_t cNodes = 0, cTris = 0, cHits = 0, cBusy = 0, cRounds = 0;
     bool have = false;          // this lane holds an unfinished traversal
-    bool parked = false;        // ... and stands at a leaf whose triangles wait for the test phase
+    KdPred parkedM = KdPred::none();   // lanes that stand at a leaf whose triangles wait for the test phase
     bool drained = false;       // wave-uniform: the work queue is exhausted
     unsigned slot = 0;          // queue slot of the ray this lane is tracing
     int prim0 = PT_PRIM_MISS;   // best among ground / spheres for that ray
     unsigned leafFirst = 0, leafCount = 0;
+    KdNode w;                   // the node a walking lane stands at
+    w.w0 = 3u; w.w1 = 0u;
 
     // The traversal of this lane is over: a triangle that beat the ground / sphere hit
     // replaces it in the ray's hit slot.
@@ -437,25 +439,26 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
         // ---- walk ----
         // (kept minimal: this loop runs once per tree level; everything that happens once per
         // leaf -- next interval, end of traversal -- is left to the test phase)
-        for (;;) {
-            if (have && !parked) {
+        const KdPred haveM = KdPred::of(have);
+        for (;;) {   // (`w` of a lane that does not walk is stale; every use is masked)
+            // the lanes' conditions are kept as wave masks (KdPred): the loop's control logic then
+            // runs on the scalar unit, and the only divergent regions are the node load and the push
+            const KdPred walkM = haveM & ~parkedM;
+            if (walkM.on()) {
                 if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
-                const KdNode w = g.kd.nodes[cur.node];
-                if ((w.w0 & 3u) != 3u) {
-                    if (cur.node_step(g.kd, w)) {   // only empty leaves below: same as standing in one
-                        leafCount = 0;
-                        parked = true;
-                    }
-                } else {
-                    leafFirst = w.w0 >> 2;
-                    leafCount = w.w1;     // may be 0: an empty leaf
-                    parked = true;
-                }
+                w = g.kd.nodes[cur.node];
             }
-            const unsigned nPark = (unsigned)__popcll(__ballot(parked));
+            const KdPred innerM = walkM & KdPred::of((w.w0 & 3u) != 3u);
+            const KdPred leafM = walkM & ~innerM;
+            const KdPred deadM = cur.node_step(g.kd, w, innerM);   // only empty leaves below: same as standing in one
+            leafFirst = leafM.on() ? (w.w0 >> 2) : leafFirst;
+            leafCount = leafM.on() ? w.w1 : (deadM.on() ? 0u : leafCount);     // may be 0: an empty leaf
+            parkedM = parkedM | leafM | deadM;
+            const unsigned nPark = parkedM.count();
             if (STATS) { if (have) cBusy++; if (lane == 0) cRounds++; }
             if (nPark == nHave || nPark >= leaf_min) break;
         }
+        const bool parked = parkedM.on();
         // ---- test ----
         {
             const unsigned cnt = parked ? leafCount : 0u;
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            parkedM = KdPred::none();
             if (parked) {
-                parked = false;
                 cur.bestT = __uint_as_float((unsigned)(__atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED) >> 32));
                 if (!cur.next_interval()) KD_FINISH();
             }

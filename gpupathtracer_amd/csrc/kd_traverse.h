@@ -62,6 +62,34 @@ inline void kd_mark_empty_children(KdNode* nodes, size_t n) {
 
 PT_HD float sel3(int axis, float x, float y, float z) { return axis == 0 ? x : (axis == 1 ? y : z); }
 
+// A per-lane truth value of the traversal's decision logic.  On the GPU it is the wave's 64-bit
+// lane mask of the condition, which lives in scalar registers: a float comparison writes such a
+// mask directly, and every '&', '|', '~' between masks is then ONE scalar instruction for the
+// whole wave, next to the vector pipeline that bounds the kernel (left as `bool`s, the compiler
+// materialises them as 0 / 1 in vector registers and combines them there).  on() turns the mask
+// back into the lane's own truth value for a select or a branch at no cost.  On the host it is
+// a plain bool.
+struct KdPred {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long m;
+    static __device__ __forceinline__ KdPred of(bool b) { KdPred p; p.m = __builtin_amdgcn_ballot_w64(b); return p; }
+    static __device__ __forceinline__ KdPred all() { KdPred p; p.m = ~0ull; return p; }
+    __device__ __forceinline__ bool on() const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    __device__ __forceinline__ KdPred operator~() const { KdPred p; p.m = ~m; return p; }
+    __device__ __forceinline__ unsigned count() const { return (unsigned)__builtin_popcountll(m); }   // lanes set (of the active ones, for a mask made by of())
+#else
+    bool m;
+    static PT_HD KdPred of(bool b) { KdPred p; p.m = b; return p; }
+    static PT_HD KdPred all() { KdPred p; p.m = true; return p; }
+    PT_HD bool on() const { return m; }
+    PT_HD KdPred operator~() const { KdPred p; p.m = !m; return p; }
+    PT_HD unsigned count() const { return m ? 1u : 0u; }
+#endif
+    static PT_HD KdPred none() { return ~all(); }
+    PT_HD KdPred operator&(KdPred b) const { KdPred p; p.m = m & b.m; return p; }
+    PT_HD KdPred operator|(KdPred b) const { KdPred p; p.m = m | b.m; return p; }
+};
+
 PT_HD float bits_to_float(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __uint_as_float(u);
@@ -159,30 +187,27 @@ struct KdCursor {
         return true;
     }
 
-    // One inner node `w`: chooses the child to enter (into `node`), defers the other one with
-    // its interval when the ray can reach it, and trims [tmin, tmax].
+    // One inner node `w`, for the lanes in `act` (the others keep their state; what they compute
+    // from a stale or dummy `w` is discarded): chooses the child to enter (into `node`), defers
+    // the other one with its interval when the ray can reach it, and trims [tmin, tmax].
     // Bits 30 / 31 of an inner node's w0 say that its left / right child is an EMPTY leaf
     // (kd_mark_empty_children; the builder's own output has them clear, and 28 bits of child
     // index).  Such a child is never entered or deferred: no load, no stack traffic.  Returns
-    // true when that leaves nothing to visit under this node (the caller moves on to the next
-    // deferred interval, exactly as it would from an empty leaf).
-    PT_HD bool node_step(const KdView& kd, KdNode w) {
+    // the lanes for which that leaves nothing to visit under this node (the caller moves on to
+    // the next deferred interval, exactly as it would from an empty leaf).
+    PT_HD KdPred node_step(const KdView& kd, KdNode w, KdPred act) {
         const int axis = (int)(w.w0 & 3u);
         const float split = bits_to_float(w.w1);
-        const uint32_t left = (w.w0 >> 2) & PT_KD_CHILD_MASK;
-        const bool emptyL = (int32_t)(w.w0 << 1) < 0, emptyR = (int32_t)w.w0 < 0;
+        const uint32_t left = (w.w0 >> 2) & PT_KD_CHILD_MASK, right = left + 1u;
+        const KdPred emptyL = KdPred::of((w.w0 & 0x40000000u) != 0u), emptyR = KdPred::of((int32_t)w.w0 < 0);
         const float oa = sel3(axis, o.x, o.y, o.z);
         // the direction enters through its reciprocal only: +-inf stands for a ray parallel to the plane
         const float ia = sel3(axis, inv.x, inv.y, inv.z);
-        // (plain '&' and '|' on purpose: every term is cheap and a short-circuit would only
-        // add branches that the lanes of a wave take differently)
         // On the plane exactly, the side the ray leaves towards comes first (a parallel ray there
         // visits both children with the whole interval, in either order).
-        const bool leftFirst = (oa < split) | ((oa == split) & (ia < 0.0f));
-        const uint32_t nearC = leftFirst ? left : left + 1u;
-        const uint32_t farC = leftFirst ? left + 1u : left;
-        const bool nearEmpty = leftFirst ? emptyL : emptyR;
-        const bool farEmpty = leftFirst ? emptyR : emptyL;
+        const KdPred leftFirst = KdPred::of(oa < split) | (KdPred::of(oa == split) & KdPred::of(ia < 0.0f));
+        const KdPred nearEmpty = (leftFirst & emptyL) | (~leftFirst & emptyR);
+        const KdPred farEmpty = (leftFirst & emptyR) | (~leftFirst & emptyL);
         // Four outcomes:
         //   near only   plane beyond the interval, or behind the origin, or ray parallel
         //               to it and outside the thickened plane
@@ -190,27 +215,32 @@ struct KdCursor {
         //               be real or lie behind the origin), or parallel inside it
         //   far only    plane crossed before the interval starts
         //   both, cut   near gets [tmin, min(tmax,hi)], far gets [max(tmin,lo), tmax]
-        const bool parallel = fabsf(ia) == INFINITY;
-        const bool inSlab = fabsf(oa - split) <= kd.sigma;
+        // (1 / d is infinite for d = 0; a finite reciprocal beyond 3e38 belongs to a ray that moves
+        // less than 1e-29 along the axis over any interval -- parallel as well.  One comparison.)
+        const KdPred parallel = KdPred::of(fabsf(ia) > 3.0e38f);
+        const KdPred inSlab = KdPred::of(fabsf(oa - split) <= kd.sigma);
         const float tp = (split - oa) * ia;
         const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
         const float lo = tp - s, hi = tp + s;
-        const bool crossing = !parallel & !((lo > tmax) | (hi < 0.0f));   // the plane is met within the interval
-        const bool behind = lo < 0.0f;
-        const bool before = hi < tmin;
-        const bool bothWhole = (parallel & inSlab) | (crossing & behind);
-        const bool farOnly = crossing & !behind & before;
-        const bool bothCut = crossing & !behind & !before;
-        const bool both = bothWhole | bothCut;
+        const KdPred crossing = ~parallel & ~(KdPred::of(lo > tmax) | KdPred::of(hi < 0.0f));   // the plane is met within the interval
+        const KdPred behind = KdPred::of(lo < 0.0f);
+        const KdPred before = KdPred::of(hi < tmin);
+        const KdPred bothWhole = (parallel & inSlab) | (crossing & behind);
+        const KdPred farOnly = crossing & ~behind & before;
+        const KdPred bothCut = crossing & ~behind & ~before;
+        const KdPred both = bothWhole | bothCut;
         // (tmin and tmax are never NaN; a NaN lo / hi compares false and leaves them as they are,
         // which is what fmaxf / fminf would do, at half the instructions)
-        const float farTmin = (bothCut & (lo > tmin)) ? lo : tmin;
-        if (both & !nearEmpty & !farEmpty) st.push(farC, farTmin, tmax);
-        const bool takeFar = farOnly | (both & nearEmpty);
-        node = takeFar ? farC : nearC;
-        tmin = (both & nearEmpty) ? farTmin : tmin;
-        tmax = (bothCut & !nearEmpty & (hi < tmax)) ? hi : tmax;
-        return takeFar ? farEmpty : nearEmpty;
+        const float farTmin = (bothCut & KdPred::of(lo > tmin)).on() ? lo : tmin;
+        if ((act & both & ~nearEmpty & ~farEmpty).on()) st.push(leftFirst.on() ? right : left, farTmin, tmax);
+        const KdPred takeFar = farOnly | (both & nearEmpty);
+        // the child entered is the right one when exactly one of "far child" and "left is near" holds
+        const KdPred pickRight = (takeFar & leftFirst) | (~takeFar & ~leftFirst);
+        const uint32_t child = pickRight.on() ? right : left;
+        node = act.on() ? child : node;
+        tmin = (act & both & nearEmpty).on() ? farTmin : tmin;
+        tmax = (act & bothCut & ~nearEmpty & KdPred::of(hi < tmax)).on() ? hi : tmax;
+        return act & ((takeFar & farEmpty) | (~takeFar & nearEmpty));
     }
 
     // One leaf visit.  Returns true when the traversal is complete.
@@ -219,7 +249,7 @@ struct KdCursor {
         if (STATS) nodesVisited++;
         while ((w.w0 & 3u) != 3u) {
             if (STATS) PT_COUNT_WAVE_ITERATION(0);
-            if (node_step(kd, w)) return !next_interval();
+            if (node_step(kd, w, KdPred::all()).on()) return !next_interval();
             w = kd.nodes[node];
             if (STATS) nodesVisited++;
         }
