@@ -351,7 +351,6 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             f[3] = p.p1.x - p.p0.x; f[4] = p.p1.y - p.p0.y; f[5] = p.p1.z - p.p0.z;   // edge1 (:230)
             f[6] = p.p2.x - p.p0.x; f[7] = p.p2.y - p.p0.y; f[8] = p.p2.z - p.p0.z;   // edge2 (:231)
             memcpy(&f[9], &i, 4);   // triangle index
-            f[10] = f[11] = 0.0f;
             float* v = &verts[9 * (size_t)i];
             v[0] = p.p0.x; v[1] = p.p0.y; v[2] = p.p0.z;
             v[3] = p.p1.x; v[4] = p.p1.y; v[5] = p.p1.z;
@@ -380,13 +379,31 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         pt::kd_mark_empty_children(reinterpret_cast<pt::KdNode*>(dev_nodes.data()), dev_nodes.size());
         // Leaf triangles: records duplicated in leaf order (a leaf visit then costs ONE memory
         // latency: the kernel is bound by dependent loads, not by footprint); only a copy beyond
-        // 16 GiB falls back to an index list into the per-triangle records.
-        bool leaf_order = tree.refs.size() * sizeof(TriRec) <= (size_t)16 << 30;
+        // 4 GiB falls back to an index list into the per-triangle records.
+        bool leaf_order = tree.refs.size() * sizeof(TriRec) <= (size_t)4 << 30;
         if (const char* e = getenv("GPT_LEAF_ORDER")) leaf_order = atoi(e) != 0;
-        std::vector<TriRec> leaf_recs;
+        // In that copy a leaf's `first` is the offset of its run in 8-byte units, and a run starts at
+        // the next 128-byte line whenever it would otherwise touch one line more than its length needs
+        // (three 40-byte records fit a line): fewer cache lines per leaf visit.
+        std::vector<uint64_t> leaf_words;   // 8-byte units
         if (leaf_order) {
-            leaf_recs.resize(dev_refs.size());
-            for (size_t r = 0; r < dev_refs.size(); r++) leaf_recs[r] = recs[(size_t)dev_refs[r]];
+            const size_t unit = sizeof(TriRec) / 8, line = 128 / 8;
+            const bool fit = getenv("GPT_NO_LINE_FIT") == nullptr;
+            std::vector<std::pair<uint32_t, uint32_t>> leaves;   // (first record, node)
+            for (size_t i = 0; i < dev_nodes.size(); i++)
+                if ((dev_nodes[i].w0 & 3u) == 3u && dev_nodes[i].w1) leaves.push_back({dev_nodes[i].w0 >> 2, (uint32_t)i});
+            std::sort(leaves.begin(), leaves.end());
+            leaf_words.reserve(dev_refs.size() * unit * 5 / 4);
+            for (const auto& lf : leaves) {
+                const size_t len = (size_t)dev_nodes[lf.second].w1 * unit;
+                size_t at = leaf_words.size();
+                if (fit && (at % line + len + line - 1) / line > (len + line - 1) / line) at = (at + line - 1) / line * line;
+                leaf_words.resize(at + len, 0);
+                for (uint32_t k = 0; k < dev_nodes[lf.second].w1; k++)
+                    memcpy(&leaf_words[at + k * unit], &recs[(size_t)dev_refs[lf.first + k]], sizeof(TriRec));
+                dev_nodes[lf.second].w0 = ((uint32_t)at << 2) | 3u;
+            }
+            if (leaf_words.size() >> 30) { st = fail(GPT_ERR_TOO_LARGE, "leaf records exceed the 30-bit offset"); break; }
         }
 
         if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
@@ -396,7 +413,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if ((st = upload(&s->d_mats, mt.packed.data(), mt.packed.size() * 4))) break;
         if ((st = upload(&s->d_nodes, dev_nodes.data(), dev_nodes.size() * 8))) break;
         if (leaf_order) {
-            if ((st = upload(&s->d_leaf_tris, leaf_recs.data(), leaf_recs.size() * sizeof(TriRec)))) break;
+            if ((st = upload(&s->d_leaf_tris, leaf_words.data(), leaf_words.size() * 8))) break;
         } else {
             if ((st = upload(&s->d_refs, dev_refs.data(), dev_refs.size() * 4))) break;
         }

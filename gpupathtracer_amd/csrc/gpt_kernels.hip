@@ -462,6 +462,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
         // ---- test ----
         {
             const unsigned cnt = parked ? leafCount : 0u;
+            const bool packed = g.kd.refs == nullptr;
+            const unsigned unit = packed ? (unsigned)(sizeof(TriRec) / 8) : 1u;
             const unsigned incl = wave_inclusive_sum(cnt);
             const unsigned excl = incl - cnt;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
@@ -480,15 +482,22 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned carry = 63u - (unsigned)__builtin_clzll(before);
                 const unsigned L = dpp_max(wave_inclusive_max(mark), carry);
                 const unsigned la = L << 2;
-                const unsigned rec0 = p + (unsigned)bperm(la, (int)(leafFirst - excl));   // owner's first record + (p - owner's first pair)
+                // owner's first record + (p - owner's first pair); in 8-byte units when the leaves hold
+                // the offsets of their packed runs, in entries of the index list otherwise
+                const unsigned r0u = unit * p + (unsigned)bperm(la, (int)(leafFirst - unit * excl));
                 const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
                 const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
                 if (p < total) {
-                    const size_t rec = g.kd.refs ? (size_t)g.kd.refs[rec0] : (size_t)rec0;
+                    const float* rp = packed ? reinterpret_cast<const float*>(g.kd.leaf_tris) + 2 * (size_t)r0u
+                                             : g.kd.leaf_tris[g.kd.refs[r0u]].f;
                     // the whole record at once (left alone, the compiler fetches `a` only after the
-                    // determinant test: a second memory latency in every chunk)
-                    const float4* rp = reinterpret_cast<const float4*>(g.kd.leaf_tris + rec);
-                    float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                    // determinant test: a second memory latency in every chunk); 8-byte aligned
+                    typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+                    typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+                    const f4a8 q0 = *reinterpret_cast<const f4a8*>(rp), q1 = *reinterpret_cast<const f4a8*>(rp + 4);
+                    const f2a8 q2 = *reinterpret_cast<const f2a8*>(rp + 8);
+                    float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w);
+                    float4 r2 = make_float4(q2.x, q2.y, 0.0f, 0.0f);
                     asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z),
                                  "+v"(r1.w), "+v"(r2.x), "+v"(r2.y));
                     const V3 a = v3(r0.x, r0.y, r0.z), e1 = v3(r0.w, r1.x, r1.y), e2 = v3(r1.z, r1.w, r2.x);

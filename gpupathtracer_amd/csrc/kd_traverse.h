@@ -20,15 +20,15 @@ namespace pt {
 
 struct KdNode { uint32_t w0, w1; };
 
-// Triangle record: a, edge1 = b - a, edge2 = c - a packed in three 16-byte
-// words: (a.x a.y a.z e1.x) (e1.y e1.z e2.x e2.y) (e2.z index - -); `index` is
-// the triangle's position in the caller's Poly array (int bits).
-struct TriRec { float f[12]; };
+// Triangle record, 40 bytes: a, edge1 = b - a, edge2 = c - a, index (int bits; the triangle's
+// position in the caller's Poly array).
+#define PT_TRI_REC_FLOATS 10
+struct TriRec { float f[PT_TRI_REC_FLOATS]; };
 
 // Leaves do not point at triangles through an index list: the records of a
 // leaf's triangles are stored contiguously in leaf order (a triangle that several
 // leaves reference is stored once per leaf), so a leaf visit reads
-// count x 48 consecutive bytes.
+// count x 40 consecutive bytes.
 struct KdView {
     const KdNode* nodes;
     const TriRec* leaf_tris;   // one record per (leaf, triangle) reference, leaf by leaf

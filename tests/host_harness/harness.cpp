@@ -38,7 +38,6 @@ static void make_recs(const float* verts, int n, std::vector<TriRec>& out) {
         f[3] = v[3] - v[0]; f[4] = v[4] - v[1]; f[5] = v[5] - v[2];
         f[6] = v[6] - v[0]; f[7] = v[7] - v[1]; f[8] = v[8] - v[2];
         memcpy(&f[9], &i, 4);
-        f[10] = f[11] = 0;
     }
 }
 

@@ -192,6 +192,33 @@ def test_kd_kernel_leaf_sizes_and_duplicate_triangles(small):
     assert np.array_equal(to, tb[sub]) and np.array_equal(tto.view(np.int32), ttb[sub].view(np.int32))
 
 
+@pytest.mark.parametrize("env", [{"GPT_LEAF_ORDER": "0"}, {"GPT_NO_LINE_FIT": "1"}])
+def test_kd_kernel_alternative_leaf_layouts(env, monkeypatch):
+    """The two other device layouts of the leaves' triangles -- an index list into per-triangle
+    records (what a copy beyond 4 GiB falls back to) and packed runs that are not fitted to
+    128-byte lines -- give the brute-force loop's hits as well."""
+    for k, val in env.items():
+        monkeypatch.setenv(k, val)
+    v, n = meshes.load_asset("monkey")
+    polys = meshes.polys_from_triangles(v, n, S.MATERIALS["glass"])
+    rng = np.random.default_rng(5)
+    m = 60000
+    pts = v.reshape(-1, 3)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    ctr, ext = (lo + hi) / 2, (hi - lo).max()
+    o = ((rng.random((m, 3), dtype=np.float32) * 3 - 1.5) * ext + ctr).astype(np.float32)
+    tgt = pts[rng.integers(0, pts.shape[0], m)] + ((rng.random((m, 3), dtype=np.float32) - 0.5) * 0.05 * ext)
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    with api.Scene(None, polys, api.render_params(max_depth=1)) as sc:
+        tk, ttk = sc.intersect(rays, use_kdtree=True)
+        tb, ttb = sc.intersect(rays, use_kdtree=False)
+    assert (tb >= 0).sum() > m // 3
+    assert np.array_equal(tk, tb)
+    assert np.array_equal(ttk.view(np.int32), ttb.view(np.int32))
+
+
 def test_image_accumulates_passes_in_order():
     """image += pass, float32, in counter order (path_tracer.cpp:100-103)."""
     w = h = 96
