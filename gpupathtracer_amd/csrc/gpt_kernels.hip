@@ -694,21 +694,43 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
 // Optionally the (single) pass alone as packed float3 for the host (the
 // reference's D2H copy, path_tracer_kernel.cu:869).
 // ---------------------------------------------------------------------------
+// A pixel's P pass values lie next to each other (16 P bytes), so a thread that walked its own
+// pixel's row would fetch one cache line per lane and load.  Instead the block stages tiles of
+// 64 pixels x 32 passes through LDS: half a wave reads the 512 contiguous bytes of one pixel's
+// 32 passes, and lane j of the first wave then adds row j in pass order.
+#define FIN_PIXELS 64
+#define FIN_PASSES 32
 __global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPasses, const float4* __restrict__ pass_rgb,
                                                       float4* __restrict__ image, float* __restrict__ pass_out3) {
-    const int stride = gridDim.x * GPT_BLOCK;
-    for (int i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < numPixels; i += stride) {
-        float4 a = image[i];
-        float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int k = 0; k < numPasses; k++) {
-            p = pass_rgb[(size_t)i * (size_t)numPasses + (size_t)k];
-            a.x += p.x; a.y += p.y; a.z += p.z; a.w += 1.0f;
+    __shared__ float4 s_tile[FIN_PIXELS][FIN_PASSES + 1];
+    const int t = (int)threadIdx.x;
+    for (int pix0 = (int)blockIdx.x * FIN_PIXELS; pix0 < numPixels; pix0 += (int)gridDim.x * FIN_PIXELS) {
+        const int i = pix0 + t;
+        const bool owner = t < FIN_PIXELS && i < numPixels;
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p = a;
+        if (owner) a = image[i];
+        for (int k0 = 0; k0 < numPasses; k0 += FIN_PASSES) {
+            const int kn = numPasses - k0 < FIN_PASSES ? numPasses - k0 : FIN_PASSES;
+            const int c = t & (FIN_PASSES - 1);
+#pragma unroll
+            for (int r = t / FIN_PASSES; r < FIN_PIXELS; r += GPT_BLOCK / FIN_PASSES)
+                if (c < kn && pix0 + r < numPixels)
+                    s_tile[r][c] = ld_stream(&pass_rgb[(size_t)(pix0 + r) * (size_t)numPasses + (size_t)(k0 + c)]);
+            __syncthreads();
+            if (owner)
+                for (int k = 0; k < kn; k++) {
+                    p = s_tile[t][k];
+                    a.x += p.x; a.y += p.y; a.z += p.z; a.w += 1.0f;
+                }
+            __syncthreads();
         }
-        image[i] = a;
-        if (pass_out3) {
-            pass_out3[3 * (size_t)i + 0] = p.x;
-            pass_out3[3 * (size_t)i + 1] = p.y;
-            pass_out3[3 * (size_t)i + 2] = p.z;
+        if (owner) {
+            image[i] = a;
+            if (pass_out3) {
+                pass_out3[3 * (size_t)i + 0] = p.x;
+                pass_out3[3 * (size_t)i + 1] = p.y;
+                pass_out3[3 * (size_t)i + 2] = p.z;
+            }
         }
     }
 }
@@ -780,7 +802,10 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
 
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3) {
-    hipLaunchKernelGGL(k_finish, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass_rgb, image, pass_out3);
+    (void)grid;   // sized here: one block per 64 pixels, at most 16 per CU's worth
+    const int blocks = (numPixels + FIN_PIXELS - 1) / FIN_PIXELS;
+    hipLaunchKernelGGL(k_finish, dim3(blocks < 4096 ? blocks : 4096), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass_rgb, image,
+                       pass_out3);
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {
