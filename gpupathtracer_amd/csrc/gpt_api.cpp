@@ -38,6 +38,7 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
                 unsigned long long* stats);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
+void gptk_extract_pass(hipStream_t s, int grid, int numPixels, int numPasses, int pass, const float4* pass_rgb, float* out3);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
 }
@@ -792,7 +793,19 @@ struct LaunchCache {
     gpt_render_params params;
     bool params_set = false;
     unsigned long long* d_sum = nullptr;
+    // look-ahead: the passes rendered beyond the one asked for, kept on the device
+    Camera cam;                 // camera of the batch in s->d_pass
+    int ahead_begin = 0, ahead_count = 0;
+    int last_counter = 0, streak = 0;
+    bool have_last = false;
 } g_launch;
+
+bool same_camera(const Camera& a, const Camera& b) {
+    return a.resolution.x == b.resolution.x && a.resolution.y == b.resolution.y && a.position.x == b.position.x &&
+           a.position.y == b.position.y && a.position.z == b.position.z && a.view.x == b.view.x && a.view.y == b.view.y &&
+           a.view.z == b.view.z && a.up.x == b.up.x && a.up.y == b.up.y && a.up.z == b.up.z && a.fov.x == b.fov.x &&
+           a.fov.y == b.fov.y && a.apertureRadius == b.apertureRadius && a.focalDistance == b.focalDistance;
+}
 
 [[noreturn]] void die(const char* what) {
     fprintf(stderr, "%s %s\n", what, g_error.c_str());
@@ -838,15 +851,49 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         gpt_render_params rp;
         if (L.params_set) rp = L.params;
         else { gpt_render_params_default(&rp); rp.row_stride_is_width = 0; }   // the reference's arithmetic
-        rp.passes_in_flight = 1;    // launchKernel traces one pass per call
+        // room for the look-ahead below (1 switches it off)
+        if (!L.params_set || rp.passes_in_flight <= 0) rp.passes_in_flight = 32;
         if (gpt_scene_create(hs.data(), numSpheres, hp.data(), numPolys, &rp, dev, &L.scene) != GPT_OK)
             die("launchKernel: scene upload failed:");
         L.polys = polys; L.spheres = spheres; L.numPolys = numPolys; L.numSpheres = numSpheres; L.checksum = sum;
+        L.ahead_count = 0;
+        L.have_last = false;
     }
-    if (L.scene->numPixels != numPixels && gpt_scene_reset(L.scene, numPixels) != GPT_OK)
-        die("launchKernel: buffer allocation failed:");
-    if (gpt_render_pass(L.scene, &renderCamera, counter, (float*)pixels) != GPT_OK)
+    gpt_scene* s = L.scene;
+    if (s->numPixels != numPixels) {
+        if (gpt_scene_reset(s, numPixels) != GPT_OK) die("launchKernel: buffer allocation failed:");
+        L.ahead_count = 0;
+    }
+    if (check_render_args(s, &renderCamera) != GPT_OK) die("launchKernel:");
+    // The reference's render loop asks for counter, counter + 1, ... with an unchanged camera until
+    // the user moves it (path_tracer.cpp:94-108).  A pass is a pure function of (scene, camera,
+    // counter), and tracing passes one at a time pays the tail of the longest paths at every depth,
+    // so a run of such calls is answered from batches traced ahead: 1, 2, 4, ... passes (at most the
+    // scene's passes_in_flight) while the run lasts; any other call starts over with a single pass.
+    const bool in_cache = L.ahead_count > 0 && same_camera(L.cam, renderCamera) && counter >= L.ahead_begin &&
+                          counter - L.ahead_begin < L.ahead_count;
+    const bool continues = L.have_last && same_camera(L.cam, renderCamera) && counter == L.last_counter + 1;
+    L.streak = continues ? L.streak + 1 : 0;
+    if (hipSetDevice(s->device) != hipSuccess) { g_error = "hipSetDevice"; die("launchKernel:"); }
+    if (!in_cache) {
+        int P = 1;
+        for (int k = 0; k < L.streak && P < s->batch; k++) P *= 2;
+        P = std::min(P, s->batch);
+        if (enqueue_batch(s, &renderCamera, counter, P, nullptr) != GPT_OK) die("launchKernel:");
+        L.cam = renderCamera;
+        L.ahead_begin = counter;
+        L.ahead_count = P;
+    }
+    L.last_counter = counter;
+    L.have_last = true;
+    gptk_extract_pass(s->stream, pixel_grid(numPixels), numPixels, L.ahead_count, counter - L.ahead_begin, s->d_pass, s->d_pass3);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(pixels, s->d_pass3, (size_t)numPixels * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) {
+        g_error = hipGetErrorString(hipGetLastError());
         die("launchKernel:");
+    }
+    if (collect_events(s) != GPT_OK) die("launchKernel:");
 }
 
 }  // extern "C"

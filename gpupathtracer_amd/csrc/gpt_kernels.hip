@@ -735,6 +735,18 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPass
     }
 }
 
+// One pass of the last batch as packed float3 (what launchKernel hands to its caller).
+__global__ __launch_bounds__(GPT_BLOCK) void k_extract_pass(int numPixels, int numPasses, int pass,
+                                                            const float4* __restrict__ pass_rgb, float* __restrict__ out3) {
+    const int stride = gridDim.x * GPT_BLOCK;
+    for (int i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < numPixels; i += stride) {
+        const float4 p = pass_rgb[(size_t)i * (size_t)numPasses + (size_t)pass];
+        out3[3 * (size_t)i + 0] = p.x;
+        out3[3 * (size_t)i + 1] = p.y;
+        out3[3 * (size_t)i + 2] = p.z;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Instrumentation and the scene checksum
 // ---------------------------------------------------------------------------
@@ -806,6 +818,10 @@ void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const fl
     const int blocks = (numPixels + FIN_PIXELS - 1) / FIN_PIXELS;
     hipLaunchKernelGGL(k_finish, dim3(blocks < 4096 ? blocks : 4096), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass_rgb, image,
                        pass_out3);
+}
+
+void gptk_extract_pass(hipStream_t s, int grid, int numPixels, int numPasses, int pass, const float4* pass_rgb, float* out3) {
+    hipLaunchKernelGGL(k_extract_pass, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass, pass_rgb, out3);
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {

@@ -286,6 +286,10 @@ void       gpt_kdtree_free(gpt_kdtree* tree);
 /* whenever the arrays' contents change.  Depth and the other constants are    */
 /* the reference's (30 bounces etc.) unless overridden with                    */
 /* gpt_launch_kernel_params().  Errors: message on stderr + exit(1).           */
+/* A run of calls with consecutive counters and an unchanged camera (the       */
+/* reference's render loop, path_tracer.cpp:94-108) is served from batches of  */
+/* up to passes_in_flight passes (32 by default here) traced ahead and kept on */
+/* the device; each call still returns exactly the pass `counter` names.       */
 /* ------------------------------------------------------------------------- */
 #ifndef GPT_NO_POD_TYPES
 void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres,

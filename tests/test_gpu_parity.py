@@ -256,6 +256,14 @@ def test_launch_kernel_drop_in():
             want0 = sc.render_pass(cam, 0)
             want1 = sc.render_pass(cam, 1)
         assert np.array_equal(px0, want0) and np.array_equal(px1, want1)
+        # a run of consecutive counters is answered from batches traced ahead; every call still returns
+        # exactly its own pass, also after the camera moves or the counter jumps
+        cam2 = S.orbit_camera(w, h, yaw=0.4)
+        calls = [(c, cam) for c in range(2, 14)] + [(14, cam2), (15, cam2), (16, cam2), (3, cam2), (17, cam), (18, cam)]
+        got = [api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, c, k) for c, k in calls]
+        with api.Scene(sph, polys, api.render_params(max_depth=8, row_stride_is_width=0)) as sc:
+            for (c, k), px in zip(calls, got):
+                assert np.array_equal(px, sc.render_pass(k, c)), c
         ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=8))
         check_pass(px0, ref["rgb"], flip_fraction=4e-3)
         # a changed scene behind the same pointers is picked up
