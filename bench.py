@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is ONE sample-per-pixel pass (launchKernel's unit of work) over the
-whole frame of the workload.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) every rank renders its own K passes -- a disjoint range
+A step is one batch of 32 sample-per-pixel passes (--spp-per-step; a pass is
+launchKernel's unit of work) over the whole frame of the workload: passes are
+traced many at a time, so a handful of steps already runs at the rate of a long
+render.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank renders its own K steps -- a disjoint range
 of pass counters, i.e. independently seeded samples -- and the float4
 accumulation images are sum-reduced once with RCCL at the end of the timed
 region; per-GPU work is fixed, so scaling is weak.
@@ -99,8 +101,9 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=32, help="sample-per-pixel passes per step")
     ap.add_argument("--workload", default="cow_heavy")
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
@@ -130,6 +133,7 @@ def main():
     distributed = world > 1 or os.environ.get("GPT_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     TRIS[0] = args.tris
@@ -139,6 +143,7 @@ def main():
     cam = api.default_camera(args.width, args.height)
     n_pix = args.width * args.height
     K, W = args.steps, args.warmup
+    Kp, Wp = K * args.spp_per_step, W * args.spp_per_step     # passes
 
     params = api.render_params(max_depth=args.depth, row_stride_is_width=1, use_kdtree=1,
                                passes_in_flight=args.batch, **({"kd_small_threshold": args.kd_small} if args.kd_small > 0 else {}))
@@ -153,8 +158,8 @@ def main():
         scene.sync()
         torch.cuda.synchronize()
 
-    # rank r owns pass counters [r*(K+W), (r+1)*(K+W)): disjoint, independently seeded samples
-    base, _ = sharding.weak_range(K + W, rank)
+    # rank r owns pass counters [r*(Kp+Wp), (r+1)*(Kp+Wp)): disjoint, independently seeded samples
+    base, _ = sharding.weak_range(Kp + Wp, rank)
 
     # ---- untimed: kd work per path-bounce (instrumented kernel), then warm-up ----
     scene.set_profiling(time_kernels=False, count_kd_work=True)
@@ -165,16 +170,16 @@ def main():
     tris_per_pb = st["kd_tris_tested"] / pb1
     hit_frac = st["hits"] / pb1
     scene.set_profiling(time_kernels=False, count_kd_work=False)
-    scene.render_range(cam, base, base + W)
+    scene.render_range(cam, base, base + Wp)
     scene.reset(n_pix)
     scene.set_profiling(time_kernels=True, count_kd_work=False)
 
     image = sharding.scene_image_tensor(scene, torch.device("cuda", local_rank))
 
-    # ---- timed region: exactly K passes per rank + the sum-reduce of the images ----
+    # ---- timed region: exactly K steps (Kp passes) per rank + the sum-reduce of the images ----
     barrier()
     t0 = time.perf_counter()
-    scene.render_range(cam, base + W, base + W + K, sync=True)
+    scene.render_range(cam, base + Wp, base + Wp + Kp, sync=True)
     sharding.sum_images(image)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -238,19 +243,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "spp_per_s": world * K / elapsed_max,
+            "ms_per_pass": elapsed_max / Kp * 1e3,
+            "spp_per_s": world * Kp / elapsed_max,
             "config": {
                 "workload": "%s: %s (%d triangles) + the reference's 14 spheres, "
-                            "ground and sky; default orbit camera %dx%d, depth %d, 1 spp per step, kd-tree"
+                            "ground and sky; default orbit camera %dx%d, depth %d, %d spp per step, kd-tree"
                             % (args.workload,
                                {"cow_heavy": "cow.obj subdivided %dx, glass" % args.subdiv,
                                 "spheres": "no mesh", "diamond_coil": "glass diamond + marble coil",
                                 "soup": "uniform random small white triangles"}[args.workload],
-                               0 if polys is None else polys.size, args.width, args.height, args.depth),
-                "passes_per_gpu": K,
+                               0 if polys is None else polys.size, args.width, args.height, args.depth, args.spp_per_step),
+                "passes_per_gpu": Kp,
                 "passes_per_launch": args.batch,
                 "parallelism": "spp-sharded x%d, one RCCL sum-reduce of the float4 image" % world,
-                "bounces_per_path": st["path_bounces"] / max(1, K * n_pix),
+                "bounces_per_path": st["path_bounces"] / max(1, Kp * n_pix),
                 "kd": dict(scene.info(), build_and_upload_s=round(t_build, 2)),
             },
             "roofline": {

@@ -57,7 +57,7 @@ json.dump({
     "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
     "path_bounces_per_launch": pb_per_launch,
     "how": "rocprofv3 --pmc, separate passes: sum(TCC_EA0_RDREQ_{32,64,128}B_sum x request size) + WRITE_SIZE*1024, "
-           "divided by the kernel's dispatches; bench.py --steps 512 --warmup 0 (8 launches of 512 passes)",
+           "divided by the kernel's dispatches; bench.py --spp-per-step 1 --steps 512 --warmup 0 (8 launches of 512 passes)",
     "source": tag + "_pmc_summary.json",
 }, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))

@@ -3,5 +3,5 @@
 # (extra bench arguments through BENCH_ARGS) and prints one compact line per run.
 var=$1; shift
 for v in "$@"; do
-  env $var=$v timeout -k 10 200 python bench.py --no-cpu-baseline --steps 256 $BENCH_ARGS 2>/dev/null | python tools/brief.py "$var=$v" || exit 1
+  env $var=$v timeout -k 10 200 python bench.py --no-cpu-baseline --spp-per-step 1 --steps 256 $BENCH_ARGS 2>/dev/null | python tools/brief.py "$var=$v" || exit 1
 done
