@@ -164,12 +164,15 @@ class Scene:
         return tri, t
 
 
-def kdtree_build(verts, small_threshold=0):
-    """Host kd-tree builder.  Returns dict(nodes[n,2] uint32, refs int32, bounds[6], max_depth)."""
+def kdtree_build(verts, small_threshold=0, on_gpu=False, device=0):
+    """kd-tree builder (host, or the same tree built on the GPU).  Returns dict(nodes[n,2] uint32, refs int32, bounds[6], max_depth)."""
     L = _lib.lib()
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
     h = ctypes.c_void_p()
-    _check(L.gpt_kdtree_build(_ptr(verts), verts.shape[0], int(small_threshold), ctypes.byref(h)))
+    if on_gpu:
+        _check(L.gpt_kdtree_build_gpu(_ptr(verts), verts.shape[0], int(small_threshold), int(device), ctypes.byref(h)))
+    else:
+        _check(L.gpt_kdtree_build(_ptr(verts), verts.shape[0], int(small_threshold), ctypes.byref(h)))
     try:
         nn, nr, md = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         bounds = np.zeros(6, dtype=np.float32)

@@ -365,7 +365,15 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         bp.small_threshold = rp.kd_small_threshold;
         if (const char* e = getenv("GPT_KD_COST")) bp.traversal_cost = (float)atof(e);
         if (const char* e = getenv("GPT_KD_EMPTY_RATIO")) bp.empty_ratio = (float)atof(e);
-        gptkd::build(verts.data(), numPolys, bp, tree);
+        // large meshes are indexed on the GPU (the same tree, word for word); GPT_KD_BUILD=host|gpu overrides
+        bool on_gpu = numPolys >= 200000;
+        if (const char* e = getenv("GPT_KD_BUILD")) on_gpu = strcmp(e, "gpu") == 0;
+        if (on_gpu) {
+            std::string berr;
+            if (!gptkd::build_gpu(verts.data(), numPolys, bp, tree, &berr)) { st = fail(GPT_ERR_HIP, berr); break; }
+        } else {
+            gptkd::build(verts.data(), numPolys, bp, tree);
+        }
         s->n_refs = (int)tree.refs.size();
         s->tree_depth = tree.max_depth;
         // device storage: nodes clustered per 128-byte line, triangle records in leaf order
@@ -747,6 +755,19 @@ gpt_status gpt_kdtree_build(const float* tri_vertices, int n_tris, int small_thr
     gptkd::BuildParams bp;
     if (small_threshold > 0) bp.small_threshold = small_threshold;
     gptkd::build(tri_vertices, n_tris, bp, t->tree);
+    *out_tree = t;
+    return GPT_OK;
+}
+gpt_status gpt_kdtree_build_gpu(const float* tri_vertices, int n_tris, int small_threshold, int device, gpt_kdtree** out_tree) {
+    if (!out_tree || n_tris < 0 || (n_tris > 0 && !tri_vertices)) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GPT_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    gpt_kdtree* t = new gpt_kdtree();
+    gptkd::BuildParams bp;
+    if (small_threshold > 0) bp.small_threshold = small_threshold;
+    std::string err;
+    if (!gptkd::build_gpu(tri_vertices, n_tris, bp, t->tree, &err)) { delete t; return fail(GPT_ERR_HIP, err); }
     *out_tree = t;
     return GPT_OK;
 }

@@ -1,6 +1,7 @@
 // kdtree_build.h -- host kd-tree builder interface (plain C++).
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace gptkd {
@@ -28,6 +29,10 @@ struct Tree {
 
 // verts: n_tris x 9 floats (p0, p1, p2).
 void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out);
+
+// The same tree -- word for word -- built on the current HIP device (kdtree_build_gpu.hip): the level-by-level
+// decisions run as kernels, numbering by prefix sums in queue order.  false: a HIP call failed (*err says which).
+bool build_gpu(const float* verts, int n_tris, const BuildParams& bp, Tree& out, std::string* err);
 
 // Device storage order of the nodes: the same tree with its nodes renumbered so that
 // every 128-byte line (16 nodes = 8 sibling pairs) holds a connected piece of the tree

@@ -271,6 +271,14 @@ gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int u
 typedef struct gpt_kdtree gpt_kdtree;
 gpt_status gpt_kdtree_build(const float* tri_vertices /* n x 9 */, int n_tris,
                             int small_threshold, gpt_kdtree** out_tree);
+/* The same tree, word for word, built by kernels on HIP device `device` (what
+ * gpt_scene_create uses for meshes of 200 000 triangles and more; the
+ * environment variable GPT_KD_BUILD=host|gpu overrides the choice there).
+ * Counterpart in the reference: the cukd builder behind constructKDTree
+ * (path_tracer_kernel.cu:740-756, cukd/kdtree.cu:81-150), with this library's
+ * deterministic rules. */
+gpt_status gpt_kdtree_build_gpu(const float* tri_vertices /* n x 9 */, int n_tris,
+                                int small_threshold, int device, gpt_kdtree** out_tree);
 gpt_status gpt_kdtree_info(const gpt_kdtree* tree, int* n_nodes, int* n_refs,
                            int* max_depth, float bounds[6]);
 gpt_status gpt_kdtree_copy(const gpt_kdtree* tree, uint32_t* nodes /* 2*n_nodes */,
