@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -85,12 +86,17 @@ MatKey mat_key(const Material& m) {
 struct MatTable {
     std::map<MatKey, int> index;
     std::vector<float> packed;   // 16 floats per material
+    MatKey last_key;
+    int last_id = -1;
     int add(const Material& m) {
         MatKey k = mat_key(m);
+        if (last_id >= 0 && memcmp(k.w, last_key.w, sizeof(k.w)) == 0) return last_id;   // meshes repeat one material
         auto it = index.find(k);
-        if (it != index.end()) return it->second;
+        if (it != index.end()) { last_key = k; last_id = it->second; return it->second; }
         int id = (int)index.size();
         index[k] = id;
+        last_key = k;
+        last_id = id;
         const AbsorptionAndScatteringProperties& as = m.medium.absorptionAndScatteringProperties;
         const float rec[16] = {
             m.diffuseColor.x, m.diffuseColor.y, m.diffuseColor.z, m.medium.refractiveIndex,
@@ -360,6 +366,9 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             int id = mt.add(p.material);
             memcpy(&nm[4 * (size_t)i + 3], &id, 4);
         }
+        const bool timing = getenv("GPT_TIMING") != nullptr;
+        auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tt0 = tnow();
         gptkd::Tree tree;
         gptkd::BuildParams bp;
         bp.small_threshold = rp.kd_small_threshold;
@@ -370,10 +379,17 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if (const char* e = getenv("GPT_KD_BUILD")) on_gpu = strcmp(e, "gpu") == 0;
         if (on_gpu) {
             std::string berr;
-            if (!gptkd::build_gpu(verts.data(), numPolys, bp, tree, &berr)) { st = fail(GPT_ERR_HIP, berr); break; }
+            if (!gptkd::build_gpu(verts.data(), numPolys, bp, tree, &berr)) {
+                // asked for explicitly: report; chosen by size: the host builder gives the same tree
+                if (getenv("GPT_KD_BUILD")) { st = fail(GPT_ERR_HIP, berr); break; }
+                fprintf(stderr, "gpt_scene_create: %s; building the kd-tree on the host instead\n", berr.c_str());
+                (void)hipGetLastError();
+                gptkd::build(verts.data(), numPolys, bp, tree);
+            }
         } else {
             gptkd::build(verts.data(), numPolys, bp, tree);
         }
+        double tt1 = tnow();
         s->n_refs = (int)tree.refs.size();
         s->tree_depth = tree.max_depth;
         // device storage: nodes clustered per 128-byte line, triangle records in leaf order
@@ -415,6 +431,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             if (leaf_words.size() >> 30) { st = fail(GPT_ERR_TOO_LARGE, "leaf records exceed the 30-bit offset"); break; }
         }
 
+        double tt2 = tnow();
         if ((st = upload(&s->d_spheres, sph.data(), sph.size() * 4))) break;
         if ((st = upload(&s->d_sphere_mat, sph_mat.data(), sph_mat.size() * 4))) break;
         if ((st = upload(&s->d_tris, recs.data(), recs.size() * sizeof(TriRec)))) break;
@@ -427,6 +444,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             if ((st = upload(&s->d_refs, dev_refs.data(), dev_refs.size() * 4))) break;
         }
 
+        if (timing) fprintf(stderr, "gpt_scene_create: kd build %.3f s, device layout %.3f s, upload %.3f s\n", tt1 - tt0, tt2 - tt1, tnow() - tt2);
         s->spill_stride = (size_t)kTraceGrid * kBlock;
         const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
         if (spill_words >> 32) { st = fail(GPT_ERR_TOO_LARGE, "kd-tree too deep for the traversal stack"); break; }
