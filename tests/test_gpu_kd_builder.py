@@ -37,3 +37,9 @@ def test_gpu_builder_degenerate_inputs():
     _compare(v.astype(np.float32), 0)
     soup = (rng.random((200000, 1, 3), dtype=np.float32) * 2 - 1) + (rng.random((200000, 3, 3), dtype=np.float32) - 0.5) * 0.02
     _compare(soup.reshape(-1, 9).astype(np.float32), 0)
+
+
+def test_gpu_builder_ten_million_triangles():
+    """The largest baseline configuration: the 10 M-triangle soup of bench.py."""
+    v, _ = meshes.random_soup(10000000, seed=12345, extent=1.0, edge=0.01)
+    _compare(np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 9), 0)
