@@ -40,6 +40,8 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
 void gptk_extract_pass(hipStream_t s, int grid, int numPixels, int numPasses, int pass, const float4* pass_rgb, float* out3);
+void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, const uint32_t* dst, const pt::TriRec* tris,
+                         unsigned long long* out);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
 }
@@ -410,25 +412,31 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         // In that copy a leaf's `first` is the offset of its run in 8-byte units, and a run starts at
         // the next 128-byte line whenever it would otherwise touch one line more than its length needs
         // (three 40-byte records fit a line): fewer cache lines per leaf visit.
-        std::vector<uint64_t> leaf_words;   // 8-byte units
+        // (the records themselves are gathered on the device from the per-triangle array: the host only
+        // numbers the runs)
+        std::vector<uint32_t> ref_dst;      // per leaf-ordered reference: offset of its record, 8-byte units
+        size_t leaf_words = 0;
         if (leaf_order) {
             const size_t unit = sizeof(TriRec) / 8, line = 128 / 8;
             const bool fit = getenv("GPT_NO_LINE_FIT") == nullptr;
-            std::vector<std::pair<uint32_t, uint32_t>> leaves;   // (first record, node)
+            std::vector<uint32_t> leaf_at(dev_refs.size() + 1, UINT32_MAX);   // first reference -> leaf node
             for (size_t i = 0; i < dev_nodes.size(); i++)
-                if ((dev_nodes[i].w0 & 3u) == 3u && dev_nodes[i].w1) leaves.push_back({dev_nodes[i].w0 >> 2, (uint32_t)i});
-            std::sort(leaves.begin(), leaves.end());
-            leaf_words.reserve(dev_refs.size() * unit * 5 / 4);
-            for (const auto& lf : leaves) {
-                const size_t len = (size_t)dev_nodes[lf.second].w1 * unit;
-                size_t at = leaf_words.size();
+                if ((dev_nodes[i].w0 & 3u) == 3u && dev_nodes[i].w1) leaf_at[dev_nodes[i].w0 >> 2] = (uint32_t)i;
+            ref_dst.resize(dev_refs.size());
+            bool ok = true;
+            for (size_t f = 0; f < dev_refs.size() && ok;) {      // the runs tile the list
+                const uint32_t nd = leaf_at[f];
+                if (nd == UINT32_MAX) { ok = false; break; }
+                const size_t cnt = dev_nodes[nd].w1, len = cnt * unit;
+                size_t at = leaf_words;
                 if (fit && (at % line + len + line - 1) / line > (len + line - 1) / line) at = (at + line - 1) / line * line;
-                leaf_words.resize(at + len, 0);
-                for (uint32_t k = 0; k < dev_nodes[lf.second].w1; k++)
-                    memcpy(&leaf_words[at + k * unit], &recs[(size_t)dev_refs[lf.first + k]], sizeof(TriRec));
-                dev_nodes[lf.second].w0 = ((uint32_t)at << 2) | 3u;
+                if ((at + len) >> 30) { ok = false; break; }
+                for (size_t k = 0; k < cnt; k++) ref_dst[f + k] = (uint32_t)(at + k * unit);
+                dev_nodes[nd].w0 = ((uint32_t)at << 2) | 3u;
+                leaf_words = at + len;
+                f += cnt;
             }
-            if (leaf_words.size() >> 30) { st = fail(GPT_ERR_TOO_LARGE, "leaf records exceed the 30-bit offset"); break; }
+            if (!ok) { st = fail(GPT_ERR_TOO_LARGE, "leaf records exceed the 30-bit offset"); break; }
         }
 
         double tt2 = tnow();
@@ -439,7 +447,20 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if ((st = upload(&s->d_mats, mt.packed.data(), mt.packed.size() * 4))) break;
         if ((st = upload(&s->d_nodes, dev_nodes.data(), dev_nodes.size() * 8))) break;
         if (leaf_order) {
-            if ((st = upload(&s->d_leaf_tris, leaf_words.data(), leaf_words.size() * 8))) break;
+            int32_t* d_refs_tmp = nullptr;
+            uint32_t* d_dst_tmp = nullptr;
+            if ((st = upload(&d_refs_tmp, dev_refs.data(), dev_refs.size() * 4))) break;
+            if ((st = upload(&d_dst_tmp, ref_dst.data(), ref_dst.size() * 4))) { (void)hipFree(d_refs_tmp); break; }
+            hipError_t he = hipMalloc((void**)&s->d_leaf_tris, std::max<size_t>(leaf_words * 8, 16));
+            if (he == hipSuccess) he = hipMemset(s->d_leaf_tris, 0, std::max<size_t>(leaf_words * 8, 16));
+            if (he == hipSuccess) {
+                gptk_gather_records(nullptr, dev_refs.size(), d_refs_tmp, d_dst_tmp, s->d_tris, (unsigned long long*)s->d_leaf_tris);
+                he = hipGetLastError();
+            }
+            if (he == hipSuccess) he = hipDeviceSynchronize();
+            (void)hipFree(d_refs_tmp);
+            (void)hipFree(d_dst_tmp);
+            if (he != hipSuccess) { st = fail(GPT_ERR_HIP, std::string("leaf records: ") + hipGetErrorString(he)); break; }
         } else {
             if ((st = upload(&s->d_refs, dev_refs.data(), dev_refs.size() * 4))) break;
         }

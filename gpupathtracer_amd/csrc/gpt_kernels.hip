@@ -735,6 +735,19 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPass
     }
 }
 
+// Leaf-ordered copy of the triangle records: reference r of the leaf-ordered list goes to the
+// 8-byte word offset dst[r] of the packed array (scene set-up, once).
+__global__ __launch_bounds__(GPT_BLOCK) void k_gather_records(size_t n_refs, const int32_t* __restrict__ refs,
+                                                              const uint32_t* __restrict__ dst, const TriRec* __restrict__ tris,
+                                                              unsigned long long* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * GPT_BLOCK + threadIdx.x;
+    if (r >= n_refs) return;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(tris + refs[r]);
+    unsigned long long* o = out + dst[r];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(TriRec) / 8); k++) o[k] = src[k];
+}
+
 // One pass of the last batch as packed float3 (what launchKernel hands to its caller).
 __global__ __launch_bounds__(GPT_BLOCK) void k_extract_pass(int numPixels, int numPasses, int pass,
                                                             const float4* __restrict__ pass_rgb, float* __restrict__ out3) {
@@ -822,6 +835,13 @@ void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const fl
 
 void gptk_extract_pass(hipStream_t s, int grid, int numPixels, int numPasses, int pass, const float4* pass_rgb, float* out3) {
     hipLaunchKernelGGL(k_extract_pass, dim3(grid), dim3(GPT_BLOCK), 0, s, numPixels, numPasses, pass, pass_rgb, out3);
+}
+
+void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, const uint32_t* dst, const TriRec* tris,
+                         unsigned long long* out) {
+    if (n_refs == 0) return;
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n_refs + GPT_BLOCK - 1) / GPT_BLOCK)), dim3(GPT_BLOCK), 0, s, n_refs, refs,
+                       dst, tris, out);
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {
