@@ -114,8 +114,14 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
         const float t = ground_t(g.ground_elevation, o, d);
         if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
     }
+    // The sphere table is read through the constant address space: it is written before the launch and
+    // never by a kernel, and only that tells the compiler that the stores around this loop cannot
+    // change it -- the loads become scalar loads (one per wave, their own wait counter) instead of
+    // vector loads whose wait also drains every store the lane has in flight.
+    typedef float cf4 __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(4))) cf4* sph = (const __attribute__((address_space(4))) cf4*)(unsigned long long)g.spheres;
     for (int s = 0; s < g.n_spheres; s++) {
-        const float4 sp = g.spheres[s];
+        const cf4 sp = sph[s];
         const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
         if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
     }
