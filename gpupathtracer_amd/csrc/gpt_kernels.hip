@@ -107,9 +107,10 @@ __device__ __forceinline__ Mat load_material(const float4* __restrict__ mats, in
 // lanes busy, and stores the result in the ray's `hit` slot; the intersect
 // kernels start from that slot and only have triangles left to test.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, float& bestT, int& prim) {
-    bestT = PT_T_START;
-    prim = PT_PRIM_MISS;
+__device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, float& bestT_out, int& prim_out) {
+    // (locals, not the caller's references: the loop bound and the running best stay in registers)
+    float bestT = PT_T_START;
+    int prim = PT_PRIM_MISS;
     if (g.ground_enabled) {
         const float t = ground_t(g.ground_elevation, o, d);
         if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
@@ -120,11 +121,13 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
     // vector loads whose wait also drains every store the lane has in flight.
     typedef float cf4 __attribute__((ext_vector_type(4)));
     const __attribute__((address_space(4))) cf4* sph = (const __attribute__((address_space(4))) cf4*)(unsigned long long)g.spheres;
-    for (int s = 0; s < g.n_spheres; s++) {
+    const int n = g.n_spheres;
+    for (int s = 0; s < n; s++) {
         const cf4 sp = sph[s];
-        const float t = sphere_t(v3(sp.x, sp.y, sp.z), sp.w, o, d);
-        if (t > 0 && t < bestT) { bestT = t; prim = PT_PRIM_SPHERE | s; }
+        if (sphere_closer(v3(sp.x, sp.y, sp.z), sp.w, o, d, bestT)) prim = PT_PRIM_SPHERE | s;
     }
+    bestT_out = bestT;
+    prim_out = prim;
 }
 
 // ---------------------------------------------------------------------------

@@ -182,6 +182,27 @@ PT_HD float sphere_t(V3 center, float radius, V3 o, V3 d) {
     if (t1 > 0 && t2 > 0) return (t1 < t2) ? t1 : t2;
     return (t1 > t2) ? t1 : t2;
 }
+// The caller's loop around sphere_t (:521-533): true, and bestT lowered, when this sphere's t
+// satisfies 0 < t < bestT.  Same arithmetic as sphere_t; everything after the radicand test sits
+// in one branch, which a wave skips altogether when none of its rays' lines meets the sphere.
+PT_HD bool sphere_closer(V3 center, float radius, V3 o, V3 d, float& bestT) {
+    V3 v = o - center;
+    float vDotDirection = dot(v, d);
+    float radicand = vDotDirection * vDotDirection - (dot(v, v) - radius * radius);
+    bool closer = false;
+    if (radicand >= 0) {            // (a NaN radicand ends without a hit in sphere_t as well)
+        float squareRoot = sqrtf(radicand);
+        float firstTerm = -vDotDirection;
+        float t1 = firstTerm + squareRoot;
+        float t2 = firstTerm - squareRoot;
+        float t;
+        if (t1 < 0 && t2 < 0) t = -1;
+        else if (t1 > 0 && t2 > 0) t = (t1 < t2) ? t1 : t2;
+        else t = (t1 > t2) ? t1 : t2;
+        if (t > 0 && t < bestT) { bestT = t; closer = true; }
+    }
+    return closer;
+}
 PT_HD V3 sphere_normal(V3 center, V3 o, V3 d, float t) {
     V3 p = o + t * d;
     return normalize(p - center);
