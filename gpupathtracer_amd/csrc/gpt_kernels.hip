@@ -155,7 +155,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
         camera_ray(cam, pixel, seed0 + pass, o, d);
         st_stream(&ray_o[i], make_float4(o.x, o.y, o.z, __int_as_float(pixel)));
         st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
-        st_stream(&thr[i], make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pass)));
+        // (no throughput is stored for a primary ray: see k_shade<true>)
         st_stream(&pass_rgb[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         float bestT;
         int prim;
@@ -554,6 +554,9 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 #endif
 #define SHADE_STAGE (SHADE_FLUSH + GPT_BLOCK)
 
+// FIRST: the launch that shades the primary rays.  k_camera stores no throughput for them: it is (1, 1, 1),
+// and slot i of the still uncompacted queue belongs to pass i - pixel * numPasses.
+template <bool FIRST>
 __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
                                                      int numPasses,
                                                      const float4* __restrict__ in_o,
@@ -599,7 +602,8 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
         if (i < n) {
             const float4 ro = ld_stream(&in_o[i]);
             const float4 rd = ld_stream(&in_d[i]);
-            const float4 th = ld_stream(&in_thr[i]);
+            const float4 th = FIRST ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i - (unsigned)__float_as_int(ro.w) * (unsigned)numPasses))
+                                    : ld_stream(&in_thr[i]);
             const float2 h = ld_stream(&hit[i]);
             o = v3(ro.x, ro.y, ro.z);
             d = v3(rd.x, rd.y, rd.z);
@@ -830,7 +834,11 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
                 int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
                 unsigned long long* stats) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
+    if (depth == 0)
+        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
+                       out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats);
+    else
+        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
                        out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats);
 }
 
