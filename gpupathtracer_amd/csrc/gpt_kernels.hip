@@ -614,27 +614,33 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
             const float bestT = h.x;
             const int prim = __float_as_int(h.y);
 
-            V3 nrm = v3(0, 1, 0);
-            Mat m = ground_material();
-            int matIndex = -1;
-            if (prim >= 0) {
-                if (prim & PT_PRIM_SPHERE) {
-                    const int s = prim & ~PT_PRIM_SPHERE;
-                    const float4 sph = g.spheres[s];
-                    nrm = sphere_normal(v3(sph.x, sph.y, sph.z), o, d, bestT);
-                    matIndex = g.sphere_mat[s];
-                } else {
-                    const float4 nm = g.tri_nm[prim];
-                    nrm = v3(nm.x, nm.y, nm.z);
-                    matIndex = __float_as_int(nm.w);
-                }
-                m = load_material(g.mats, matIndex);
-            }
+            // Everything that depends on the inputs alone is requested at once (the medium's
+            // coefficients, the sphere or the triangle's normal and material index), then the material;
+            // the sphere normal is worked out while the material is on its way.
+            const bool isSphere = prim >= 0 && (prim & PT_PRIM_SPHERE) != 0;
+            const bool isTri = prim >= 0 && !isSphere;
             V3 sa = v3(0, 0, 0);
             float ss = 0.0f;
+            float4 m2 = make_float4(0, 0, 0, 0), m3 = m2, geo = m2;
+            int matIndex = -1;
             if (medium >= 0) {
-                const float4 m2 = g.mats[4 * medium + 2];
-                const float4 m3 = g.mats[4 * medium + 3];
+                m2 = g.mats[4 * medium + 2];
+                m3 = g.mats[4 * medium + 3];
+            }
+            if (isSphere) {
+                const int s = prim & ~PT_PRIM_SPHERE;
+                geo = g.spheres[s];
+                matIndex = g.sphere_mat[s];
+            } else if (isTri) {
+                geo = g.tri_nm[prim];
+                matIndex = __float_as_int(geo.w);
+            }
+            Mat m = ground_material();
+            if (prim >= 0) m = load_material(g.mats, matIndex);
+            V3 nrm = v3(0, 1, 0);
+            if (isSphere) nrm = sphere_normal(v3(geo.x, geo.y, geo.z), o, d, bestT);
+            else if (isTri) nrm = v3(geo.x, geo.y, geo.z);
+            if (medium >= 0) {
                 ss = m2.w;
                 sa = v3(m3.x, m3.y, m3.z);
             }
