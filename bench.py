@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10000000, help="triangle count of the soup workload")
-    ap.add_argument("--batch", type=int, default=512, help="passes traced together per launch")
+    ap.add_argument("--batch", type=int, default=0, help="passes traced together per launch (0: what fits half of the free device memory, at most 512)")
     ap.add_argument("--kd-small", type=int, default=0, help="kd builder: node size at which the SAH stage takes over (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
@@ -230,6 +230,7 @@ def main():
                 traffic = None
         if kernel != "k_intersect_kd<false>":
             traffic = None
+        info = scene.info()
         out = {
             "metric": "Mpath-bounces/s",
             "value": total_pb / elapsed_max / 1e6,
@@ -254,10 +255,10 @@ def main():
                                 "soup": "uniform random small white triangles"}[args.workload],
                                0 if polys is None else polys.size, args.width, args.height, args.depth, args.spp_per_step),
                 "passes_per_gpu": Kp,
-                "passes_per_launch": args.batch,
+                "passes_per_launch": info.pop("passes_in_flight"),
                 "parallelism": "spp-sharded x%d, one RCCL sum-reduce of the float4 image" % world,
                 "bounces_per_path": st["path_bounces"] / max(1, Kp * n_pix),
-                "kd": dict(scene.info(), build_and_upload_s=round(t_build, 2)),
+                "kd": dict(info, build_and_upload_s=round(t_build, 2)),
             },
             "roofline": {
                 "kernel": kernel,

@@ -145,7 +145,7 @@ class Scene:
     def info(self):
         a, b, c, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _check(_lib.lib().gpt_scene_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
-        return {"kd_nodes": a.value, "kd_refs": b.value, "kd_depth": c.value}
+        return {"kd_nodes": a.value, "kd_refs": b.value, "kd_depth": c.value, "passes_in_flight": d.value}
 
     def primary_hits(self, camera, counter):
         cam = _cam(camera)

@@ -676,12 +676,12 @@ gpt_status gpt_get_stats(gpt_scene* s, gpt_stats* out) {
     return GPT_OK;
 }
 
-gpt_status gpt_scene_info(gpt_scene* s, int* n_nodes, int* n_refs, int* tree_depth, int* n_materials) {
+gpt_status gpt_scene_info(gpt_scene* s, int* n_nodes, int* n_refs, int* tree_depth, int* passes_in_flight) {
     if (!s) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene");
     if (n_nodes) *n_nodes = s->n_nodes;
     if (n_refs) *n_refs = s->n_refs;
     if (tree_depth) *tree_depth = s->tree_depth;
-    (void)n_materials;
+    if (passes_in_flight) *passes_in_flight = s->numPixels > 0 ? s->batch : 0;
     return GPT_OK;
 }
 

@@ -244,8 +244,9 @@ gpt_status gpt_get_stats(gpt_scene* scene, gpt_stats* out);
  * report the sums in gpt_stats.device_ms_*.  count_kd_work: run the
  * instrumented intersect kernel that counts kd nodes visited / triangles tested. */
 gpt_status gpt_scene_set_profiling(gpt_scene* scene, int time_kernels, int count_kd_work);
-/* Size of the scene's kd-tree. */
-gpt_status gpt_scene_info(gpt_scene* scene, int* n_nodes, int* n_refs, int* tree_depth, int* reserved);
+/* Size of the scene's kd-tree, and the number of passes traced together per
+ * launch that the last gpt_scene_reset settled on (0 before the first one). */
+gpt_status gpt_scene_info(gpt_scene* scene, int* n_nodes, int* n_refs, int* tree_depth, int* passes_in_flight);
 
 /* First-hit record of every primary ray of pass `counter` (debug/parity):
  * prim[i] = -1 miss, -2 ground, 0x40000000|s sphere s, otherwise triangle
