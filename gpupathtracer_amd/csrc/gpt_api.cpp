@@ -67,7 +67,10 @@ gpt_status fail(gpt_status st, const std::string& msg) {
     } while (0)
 
 const int kBlock = 256;
-const int kTraceGrid = 2048;        // persistent grid of the intersect / shade kernels
+#ifndef GPT_TRACE_GRID
+#define GPT_TRACE_GRID 2048
+#endif
+const int kTraceGrid = GPT_TRACE_GRID;   // persistent grid of the intersect / shade kernels
 
 struct MatKey {
     uint32_t w[15];
