@@ -72,6 +72,7 @@ SYMBOLS = {
     "gpt_tonemap_8bit": (None, [_V, _I, _I, _V]),
     "gpt_write_ppm": (_I, [ctypes.c_char_p, _V, _I, _I, _I]),
     "gpt_write_pfm": (_I, [ctypes.c_char_p, _V, _I, _I, _I]),
+    "gpt_write_exr": (_I, [ctypes.c_char_p, _V, _I, _I, _I]),
 }
 
 

@@ -244,6 +244,11 @@ def write_pfm(path, sum_rgb, width, height, passes):
     _check(_lib.lib().gpt_write_pfm(path.encode(), _ptr(sum_rgb), int(width), int(height), int(passes)))
 
 
+def write_exr(path, sum_rgb, width, height, passes):
+    sum_rgb = np.ascontiguousarray(sum_rgb, dtype=np.float32)
+    _check(_lib.lib().gpt_write_exr(path.encode(), _ptr(sum_rgb), int(width), int(height), int(passes)))
+
+
 # ---- the reference-compatible entry point -------------------------------------
 def device_alloc(nbytes):
     p = ctypes.c_void_p()

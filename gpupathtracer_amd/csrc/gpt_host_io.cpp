@@ -205,6 +205,73 @@ gpt_status gpt_write_pfm(const char* path, const float* sum_rgb, int width, int 
     return GPT_OK;
 }
 
+// OpenEXR 2 scanline file, uncompressed, three 32-bit float channels (stored in the
+// alphabetical order B, G, R the format prescribes), row 0 at the top (lineOrder INCREASING_Y).
+namespace {
+void exr_put(std::vector<unsigned char>& b, const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    b.insert(b.end(), c, c + n);
+}
+void exr_i32(std::vector<unsigned char>& b, int32_t v) { exr_put(b, &v, 4); }      // (little-endian host)
+void exr_f32(std::vector<unsigned char>& b, float v) { exr_put(b, &v, 4); }
+void exr_str(std::vector<unsigned char>& b, const char* s) { exr_put(b, s, strlen(s) + 1); }
+void exr_attr(std::vector<unsigned char>& b, const char* name, const char* type, const std::vector<unsigned char>& value) {
+    exr_str(b, name);
+    exr_str(b, type);
+    exr_i32(b, (int32_t)value.size());
+    b.insert(b.end(), value.begin(), value.end());
+}
+}  // namespace
+
+gpt_status gpt_write_exr(const char* path, const float* sum_rgb, int width, int height, int passes) {
+    if (!path || !sum_rgb || width <= 0 || height <= 0 || passes <= 0)
+        return io_fail(GPT_ERR_INVALID_ARGUMENT, "bad argument to gpt_write_exr");
+    std::vector<unsigned char> hd;
+    exr_i32(hd, 20000630);     // magic
+    exr_i32(hd, 2);            // version 2, single-part scanline, no long names
+    {
+        std::vector<unsigned char> v;
+        for (const char* ch : {"B", "G", "R"}) {
+            exr_str(v, ch);
+            exr_i32(v, 2);                         // pixel type FLOAT
+            v.push_back(0); v.push_back(0); v.push_back(0); v.push_back(0);   // pLinear + reserved
+            exr_i32(v, 1);                         // x sampling
+            exr_i32(v, 1);                         // y sampling
+        }
+        v.push_back(0);
+        exr_attr(hd, "channels", "chlist", v);
+    }
+    { std::vector<unsigned char> v(1, 0); exr_attr(hd, "compression", "compression", v); }            // NO_COMPRESSION
+    for (const char* name : {"dataWindow", "displayWindow"}) {
+        std::vector<unsigned char> v;
+        exr_i32(v, 0); exr_i32(v, 0); exr_i32(v, width - 1); exr_i32(v, height - 1);
+        exr_attr(hd, name, "box2i", v);
+    }
+    { std::vector<unsigned char> v(1, 0); exr_attr(hd, "lineOrder", "lineOrder", v); }                // INCREASING_Y
+    { std::vector<unsigned char> v; exr_f32(v, 1.0f); exr_attr(hd, "pixelAspectRatio", "float", v); }
+    { std::vector<unsigned char> v; exr_f32(v, 0.0f); exr_f32(v, 0.0f); exr_attr(hd, "screenWindowCenter", "v2f", v); }
+    { std::vector<unsigned char> v; exr_f32(v, 1.0f); exr_attr(hd, "screenWindowWidth", "float", v); }
+    hd.push_back(0);           // end of header
+    FILE* f = fopen(path, "wb");
+    if (!f) return io_fail(GPT_ERR_IO, std::string("cannot open ") + path);
+    const size_t row_bytes = 8 + (size_t)width * 12;          // y, byte count, three channel rows
+    std::vector<uint64_t> offsets((size_t)height);
+    for (int y = 0; y < height; y++) offsets[(size_t)y] = hd.size() + (size_t)height * 8 + (size_t)y * row_bytes;
+    bool ok = fwrite(hd.data(), 1, hd.size(), f) == hd.size() &&
+              fwrite(offsets.data(), 8, offsets.size(), f) == offsets.size();
+    std::vector<unsigned char> row;
+    for (int y = 0; y < height && ok; y++) {
+        row.clear();
+        exr_i32(row, y);
+        exr_i32(row, width * 12);
+        for (int c = 2; c >= 0; c--)                                      // B, G, R
+            for (int x = 0; x < width; x++) exr_f32(row, sum_rgb[((size_t)y * width + x) * 3 + c] / (float)passes);
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    fclose(f);
+    return ok ? GPT_OK : io_fail(GPT_ERR_IO, "short write");
+}
+
 // objLoader::objLoader (objcore/objloader.cpp:18-122) + PathTracer::prepMesh
 // (path_tracer.cpp:52-69) + the poly loop of createDeviceData (:275-278).
 gpt_status gpt_obj_load(const char* path, const Material* material, Poly** out_polys, int* out_numPolys,

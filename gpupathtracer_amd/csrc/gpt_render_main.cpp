@@ -13,7 +13,7 @@
 
 static void usage() {
     fprintf(stderr,
-            "usage: gpt_render [--width W] [--height H] [--spp N] [--depth D] [--out image.ppm] [--pfm image.pfm]\n"
+            "usage: gpt_render [--width W] [--height H] [--spp N] [--depth D] [--out image.ppm] [--pfm image.pfm] [--exr image.exr]\n"
             "                  [--obj mesh.obj [--material NAME] [--scale S] [--translate X Y Z]] [--no-spheres]\n"
             "                  [--yaw R] [--pitch R] [--radius R] [--aperture R] [--fovx DEG] [--center X Y Z]\n"
             "                  [--brute-force] [--device N]\n");
@@ -21,7 +21,7 @@ static void usage() {
 
 int main(int argc, char** argv) {
     int width = 512, height = 512, spp = 64, depth = 30, device = 0;   // display.cpp:33-34, MAX_TRACE_DEPTH
-    std::string out = "render.ppm", pfm, obj, material = "glass";
+    std::string out = "render.ppm", pfm, exr, obj, material = "glass";
     float scale = 1, tr[3] = {0, 0, 0};
     float yaw = 0, pitch = 0.3f, radius = 4, aperture = 0.04f, fovx = 45, center[3] = {0, 0, 0};
     bool spheres_on = true, brute = false;
@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--pfm") { need(1); pfm = argv[++i]; }
+        else if (a == "--exr") { need(1); exr = argv[++i]; }
         else if (a == "--obj") { need(1); obj = argv[++i]; }
         else if (a == "--material") { need(1); material = argv[++i]; }
         else if (a == "--scale") { need(1); scale = (float)atof(argv[++i]); }
@@ -99,6 +100,7 @@ int main(int argc, char** argv) {
            (double)st.path_bounces / (sec > 0 ? sec : 1) / 1e6);
     if (gpt_write_ppm(out.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     if (!pfm.empty() && gpt_write_pfm(pfm.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+    if (!exr.empty() && gpt_write_exr(exr.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     gpt_scene_destroy(scene);
     gpt_free(polys);
     return 0;

@@ -351,6 +351,9 @@ void gpt_tonemap_8bit(const float* sum_rgb, int numPixels, int passes, unsigned 
 gpt_status gpt_write_ppm(const char* path, const float* sum_rgb, int width, int height, int passes);
 /* Little-endian PFM (PF) of sum/passes, raw float radiance. */
 gpt_status gpt_write_pfm(const char* path, const float* sum_rgb, int width, int height, int passes);
+/* OpenEXR 2 scanline file of sum/passes: uncompressed, 32-bit float channels B, G, R,
+ * row 0 at the top (the headless replacement of the PBO display, display.cpp:195-216). */
+gpt_status gpt_write_exr(const char* path, const float* sum_rgb, int width, int height, int passes);
 
 #ifdef __cplusplus
 }

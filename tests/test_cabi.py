@@ -95,6 +95,31 @@ def test_tonemap_matches_oracle_and_ppm_pfm_roundtrip(tmp_path):
     data = np.frombuffer(raw[len(header):], dtype="<f4").reshape(h, w, 3)[::-1]   # PFM rows bottom-up
     want = (img / np.float32(passes)).reshape(h, w, 3)
     assert np.array_equal(data[~np.isnan(want)], want[~np.isnan(want)])
+    # OpenEXR: header attributes, offset table and uncompressed B, G, R float scanlines
+    import struct
+    exr = str(tmp_path / "a.exr")
+    api.write_exr(exr, img, w, h, passes)
+    raw = open(exr, "rb").read()
+    assert struct.unpack_from("<ii", raw, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        name_end = raw.index(b"\0", pos); type_end = raw.index(b"\0", name_end + 1)
+        size = struct.unpack_from("<i", raw, type_end + 1)[0]
+        attrs[raw[pos:name_end].decode()] = (raw[name_end + 1:type_end].decode(), raw[type_end + 5:type_end + 5 + size])
+        pos = type_end + 5 + size
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1) and attrs["dataWindow"][0] == "box2i"
+    assert attrs["channels"][1].count(b"\0") and attrs["channels"][1].startswith(b"B\0") and b"G\0" in attrs["channels"][1]
+    offsets = struct.unpack_from("<%dQ" % h, raw, pos)
+    for y in (0, h // 2, h - 1):
+        yy, nbytes = struct.unpack_from("<ii", raw, offsets[y])
+        assert (yy, nbytes) == (y, w * 12)
+        bgr = np.frombuffer(raw, dtype="<f4", count=3 * w, offset=offsets[y] + 8).reshape(3, w)
+        row = want[y]
+        ok = ~np.isnan(row)
+        assert np.array_equal(bgr[::-1].T[ok], row[ok])
+    assert offsets[-1] + 8 + w * 12 == len(raw)
     with pytest.raises(api.GptError):
         api.write_ppm(str(tmp_path / "nodir" / "x.ppm"), img, w, h, passes)
 
