@@ -126,6 +126,37 @@ PT_HD int load_tri(const TriRec* tris, size_t slot, V3& a, V3& e1, V3& e2) {
     return float_to_int_bits(f[9]);
 }
 
+// The part of the ray within [0, t_limit] that lies inside the root box padded by the slack; false:
+// none (or a NaN component: such a ray hits nothing in the reference's loop -- every comparison of its
+// triangle test fails -- and must not wander through the tree either).  `inv` receives 1 / d.
+PT_HD bool kd_root_interval(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv, float& tmin, float& tmax) {
+    if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return false;
+    tmin = 0.0f;
+    tmax = t_limit;
+    inv = v3(kd_rcp(d.x), kd_rcp(d.y), kd_rcp(d.z));
+    const float oc[3] = {o.x, o.y, o.z};
+    const float dc[3] = {d.x, d.y, d.z};
+    const float ic[3] = {inv.x, inv.y, inv.z};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < 3; a++) {
+        float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
+        if (dc[a] != 0.0f) {
+            float iv = ic[a];
+            float ta = (lo - oc[a]) * iv, tb = (hi - oc[a]) * iv;
+            float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+            tn -= PT_KD_REL_SLACK * fabsf(tn);
+            tf += PT_KD_REL_SLACK * fabsf(tf);
+            tmin = fmaxf(tmin, tn);
+            tmax = fminf(tmax, tf);
+        } else if (!(oc[a] >= lo && oc[a] <= hi)) {
+            return false;
+        }
+    }
+    return tmin <= tmax;
+}
+
 // Stack concept: void reset(); void push(uint32_t node, float tmin, float tmax);
 //                bool pop(uint32_t& node, float& tmin, float& tmax);
 //
@@ -146,33 +177,9 @@ struct KdCursor {
     // false: the ray cannot hit any triangle (it misses the padded root box).
     PT_HD bool begin(const KdView& kd, V3 o_, V3 d_, float t_limit) {
         o = o_; d = d_;
-        // a ray with a NaN component hits nothing in the reference's loop (every comparison of
-        // its triangle test fails); it must not wander through the tree either
-        if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return false;
         bestT = t_limit;
         bestTri = -1;
-        tmin = 0.0f;
-        tmax = t_limit;
-        inv = v3(kd_rcp(d.x), kd_rcp(d.y), kd_rcp(d.z));
-        const float oc[3] = {o.x, o.y, o.z};
-        const float dc[3] = {d.x, d.y, d.z};
-        const float ic[3] = {inv.x, inv.y, inv.z};
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
-            if (dc[a] != 0.0f) {
-                float iv = ic[a];
-                float ta = (lo - oc[a]) * iv, tb = (hi - oc[a]) * iv;
-                float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
-                tn -= PT_KD_REL_SLACK * fabsf(tn);
-                tf += PT_KD_REL_SLACK * fabsf(tf);
-                tmin = fmaxf(tmin, tn);
-                tmax = fminf(tmax, tf);
-            } else if (!(oc[a] >= lo && oc[a] <= hi)) {
-                return false;
-            }
-        }
-        if (!(tmin <= tmax)) return false;
+        if (!kd_root_interval(kd, o, d, t_limit, inv, tmin, tmax)) return false;
         node = 0;
         st.reset();
         return true;
