@@ -61,6 +61,7 @@ SYMBOLS = {
     "gpt_launch_kernel_params": (None, [_V]),
     "gpt_device_alloc": (_I, [c_void_pp, ctypes.c_size_t]),
     "gpt_device_upload": (_I, [_V, _V, ctypes.c_size_t]),
+    "gpt_device_download": (_I, [_V, _V, ctypes.c_size_t]),
     "gpt_device_free": (_I, [_V]),
     "gpt_obj_load": (_I, [ctypes.c_char_p, _V, c_void_pp, ctypes.POINTER(_I), _V]),
     "gpt_free": (None, [_V]),

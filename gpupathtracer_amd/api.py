@@ -261,6 +261,12 @@ def device_upload(dst, host_array):
     _check(_lib.lib().gpt_device_upload(dst, _ptr(host_array), host_array.nbytes))
 
 
+def device_download(src, nbytes, dtype=np.uint8):
+    out = np.empty(int(nbytes) // np.dtype(dtype).itemsize, dtype=dtype)
+    _check(_lib.lib().gpt_device_download(_ptr(out), src, out.nbytes))
+    return out
+
+
 def device_free(p):
     _check(_lib.lib().gpt_device_free(p))
 

@@ -66,6 +66,28 @@ gpt_status fail(gpt_status st, const std::string& msg) {
         }                                                                                     \
     } while (0)
 
+// Makes `device` the calling thread's current device for the lifetime of the guard and restores the
+// caller's own device afterwards, so that no entry point moves the caller's later allocations and
+// launches to another GPU.
+struct DeviceGuard {
+    int prev = -1;
+    bool good = false;
+    explicit DeviceGuard(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur == device) { good = true; return; }
+        good = hipSetDevice(device) == hipSuccess;
+        if (good) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    bool ok() const { return good; }
+};
+#define GPT_ON_DEVICE(dev)                                             \
+    DeviceGuard device_guard_(dev);                                    \
+    if (!device_guard_.ok()) return fail(GPT_ERR_HIP, "hipSetDevice failed")
+
 const int kBlock = 256;
 #ifndef GPT_TRACE_GRID
 #define GPT_TRACE_GRID 2048
@@ -330,7 +352,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(GPT_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(GPT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
+    GPT_ON_DEVICE(device);
 
     gpt_scene* s = new gpt_scene();
     s->device = device;
@@ -513,7 +535,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
 
 gpt_status gpt_scene_destroy(gpt_scene* s) {
     if (!s) return GPT_OK;
-    (void)hipSetDevice(s->device);
+    DeviceGuard device_guard_(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     free_pixel_buffers(s);
     void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_refs, s->d_tri_nm, s->d_mats, s->d_nodes,
@@ -527,7 +549,7 @@ gpt_status gpt_scene_destroy(gpt_scene* s) {
 
 gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
     if (!s || numPixels <= 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad scene or pixel count");
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
     gpt_status st = collect_events(s);
     if (st) return st;
@@ -568,7 +590,7 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
 gpt_status gpt_render_pass(gpt_scene* s, const Camera* cam, int counter, float* host_pixels) {
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     if ((st = enqueue_batch(s, cam, counter, 1, host_pixels ? s->d_pass3 : nullptr))) return st;
     if (host_pixels) {
         HIP_TRY(hipMemcpyAsync(host_pixels, s->d_pass3, (size_t)s->numPixels * 3 * sizeof(float),
@@ -581,7 +603,7 @@ gpt_status gpt_render_pass(gpt_scene* s, const Camera* cam, int counter, float* 
 gpt_status gpt_render_range(gpt_scene* s, const Camera* cam, int counter_begin, int counter_end, int sync) {
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     for (int c = counter_begin; c < counter_end; c += s->batch) {
         const int P = std::min(s->batch, counter_end - c);
         if ((st = enqueue_batch(s, cam, c, P, nullptr))) return st;
@@ -599,7 +621,7 @@ gpt_status gpt_render_range(gpt_scene* s, const Camera* cam, int counter_begin, 
 
 gpt_status gpt_scene_sync(gpt_scene* s) {
     if (!s) return fail(GPT_ERR_INVALID_ARGUMENT, "null scene");
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
     return collect_events(s);
 }
@@ -622,7 +644,7 @@ gpt_status gpt_accum_device_ptr(gpt_scene* s, void** out_ptr, size_t* out_bytes)
 
 gpt_status gpt_accum_download(gpt_scene* s, float* host_rgb, int* out_passes) {
     if (!s || !s->d_image || !host_rgb) return fail(GPT_ERR_INVALID_ARGUMENT, "no image or null output");
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
     std::vector<float> tmp((size_t)s->numPixels * 4);
     HIP_TRY(hipMemcpy(tmp.data(), s->d_image, tmp.size() * 4, hipMemcpyDeviceToHost));
@@ -637,7 +659,7 @@ gpt_status gpt_accum_download(gpt_scene* s, float* host_rgb, int* out_passes) {
 
 gpt_status gpt_accum_upload(gpt_scene* s, const float* host_rgb, int passes) {
     if (!s || !s->d_image || !host_rgb) return fail(GPT_ERR_INVALID_ARGUMENT, "no image or null input");
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
     std::vector<float> tmp((size_t)s->numPixels * 4);
     for (size_t i = 0; i < (size_t)s->numPixels; i++) {
@@ -692,7 +714,7 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
     if (!prim || !t) return fail(GPT_ERR_INVALID_ARGUMENT, "null output");
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     const int N = s->numPixels;
     const CamPre cp = make_cam(cam, s->params.row_stride_is_width);
     unsigned* counts = s->d_counters;
@@ -730,7 +752,7 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
 gpt_status gpt_debug_intersect(gpt_scene* s, const float* rays, int n, int use_kdtree, int32_t* tri, float* t) {
     if (!s || !rays || !tri || !t || n < 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
     if (n == 0) return GPT_OK;
-    HIP_TRY(hipSetDevice(s->device));
+    GPT_ON_DEVICE(s->device);
     if (s->geom.n_tris == 0) {
         for (int i = 0; i < n; i++) { tri[i] = -1; t[i] = PT_T_START; }
         return GPT_OK;
@@ -804,7 +826,7 @@ gpt_status gpt_kdtree_build_gpu(const float* tri_vertices, int n_tris, int small
     if (!out_tree || n_tris < 0 || (n_tris > 0 && !tri_vertices)) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GPT_ERR_NO_DEVICE, "no HIP device");
-    HIP_TRY(hipSetDevice(device));
+    GPT_ON_DEVICE(device);
     gpt_kdtree* t = new gpt_kdtree();
     gptkd::BuildParams bp;
     if (small_threshold > 0) bp.small_threshold = small_threshold;
@@ -838,6 +860,11 @@ gpt_status gpt_device_alloc(void** out_ptr, size_t bytes) {
 gpt_status gpt_device_upload(void* dst_device, const void* src_host, size_t bytes) {
     if (bytes == 0) return GPT_OK;
     HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+gpt_status gpt_device_download(void* dst_host, const void* src_device, size_t bytes) {
+    if (bytes == 0) return GPT_OK;
+    HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
     return GPT_OK;
 }
 gpt_status gpt_device_free(void* ptr) {
@@ -937,7 +964,8 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
                           counter - L.ahead_begin < L.ahead_count;
     const bool continues = L.have_last && same_camera(L.cam, renderCamera) && counter == L.last_counter + 1;
     L.streak = continues ? L.streak + 1 : 0;
-    if (hipSetDevice(s->device) != hipSuccess) { g_error = "hipSetDevice"; die("launchKernel:"); }
+    DeviceGuard device_guard_(s->device);
+    if (!device_guard_.ok()) { g_error = "hipSetDevice"; die("launchKernel:"); }
     if (!in_cache) {
         int P = 1;
         for (int k = 0; k < L.streak && P < s->batch; k++) P *= 2;

@@ -147,7 +147,10 @@ const char* gpt_last_error(void);
 /* ------------------------------------------------------------------------- */
 /* Render parameters.  The reference hard-codes these as #defines             */
 /* (path_tracer_kernel.cu:46-50); gpt_render_params_default() returns exactly */
-/* those values except max_depth, which callers normally lower.               */
+/* those values (max_depth 30 included).  The fields the reference has no     */
+/* counterpart for default to row_stride_is_width = 1 and use_kdtree = 1:     */
+/* both deviate from its behaviour as described at the fields (launchKernel   */
+/* itself keeps row_stride_is_width = 0).                                     */
 /* ------------------------------------------------------------------------- */
 typedef struct gpt_render_params {
     int    max_depth;         /* MAX_TRACE_DEPTH, 30                    (:47)  */
@@ -310,6 +313,7 @@ void gpt_launch_kernel_params(const gpt_render_params* params);
  * of their own (the reference used cudaMalloc/cudaMemcpy/cudaFree). */
 gpt_status gpt_device_alloc(void** out_ptr, size_t bytes);
 gpt_status gpt_device_upload(void* dst_device, const void* src_host, size_t bytes);
+gpt_status gpt_device_download(void* dst_host, const void* src_device, size_t bytes);
 gpt_status gpt_device_free(void* ptr);
 
 /* ------------------------------------------------------------------------- */
