@@ -164,6 +164,14 @@ class Scene:
         return tri, t
 
 
+NOALLOC_MAX_RAYS = 16384
+
+
+def intersect_noalloc(scene, d_rays, n, d_tri, d_t, use_kdtree=True):
+    """gpt_intersect_noalloc: device pointers in and out, no allocation inside the call."""
+    _check(_lib.lib().gpt_intersect_noalloc(scene._h, d_rays, int(n), 1 if use_kdtree else 0, d_tri, d_t))
+
+
 def kdtree_build(verts, small_threshold=0, on_gpu=False, device=0):
     """kd-tree builder (host, or the same tree built on the GPU).  Returns dict(nodes[n,2] uint32, refs int32, bounds[6], max_depth)."""
     L = _lib.lib()

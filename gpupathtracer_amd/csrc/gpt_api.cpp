@@ -810,6 +810,93 @@ gpt_status gpt_debug_intersect(gpt_scene* s, const float* rays, int n, int use_k
     return st;
 }
 
+// ---- closest-hit query that allocates nothing -----------------------------------
+// gpt_intersect_noalloc: gpt_debug_intersect for callers that cannot allocate device memory.
+// Everything the query needs beyond its inputs and outputs -- the ray queue in the kernels'
+// layout, the hit slots, the queue counters, the statistics words and the spill part of the
+// traversal stacks -- lives in ONE file-scope device array.  Every GPU holds its own copy of that
+// array at its own address; g_noalloc_ptr[device] is that address, looked up once per device.
+#define GPT_NOALLOC_SPILL_LEVELS 64
+#define GPT_NOALLOC_THREADS GPT_NOALLOC_MAX_RAYS   /* one traversal thread per ray at most */
+#define GPT_NOALLOC_OFF_RAY_O 0ull
+#define GPT_NOALLOC_OFF_RAY_D (GPT_NOALLOC_OFF_RAY_O + 16ull * GPT_NOALLOC_MAX_RAYS)
+#define GPT_NOALLOC_OFF_HIT (GPT_NOALLOC_OFF_RAY_D + 16ull * GPT_NOALLOC_MAX_RAYS)
+#define GPT_NOALLOC_OFF_COUNTERS (GPT_NOALLOC_OFF_HIT + 8ull * GPT_NOALLOC_MAX_RAYS)
+#define GPT_NOALLOC_COUNTER_BYTES ((4ull * GPT_COUNTER_WORDS + 255ull) / 256ull * 256ull)
+#define GPT_NOALLOC_OFF_STATS (GPT_NOALLOC_OFF_COUNTERS + GPT_NOALLOC_COUNTER_BYTES)
+#define GPT_NOALLOC_STAT_BYTES ((8ull * GPT_STAT_WORDS + 255ull) / 256ull * 256ull)
+#define GPT_NOALLOC_OFF_SPILL (GPT_NOALLOC_OFF_STATS + GPT_NOALLOC_STAT_BYTES)
+#define GPT_NOALLOC_SPILL_BYTES (4ull * 3ull * GPT_NOALLOC_SPILL_LEVELS * GPT_NOALLOC_THREADS)
+#define GPT_NOALLOC_BYTES (GPT_NOALLOC_OFF_SPILL + GPT_NOALLOC_SPILL_BYTES)
+
+static __device__ __align__(256) unsigned char scratch[GPT_NOALLOC_BYTES];
+
+namespace {
+const int kMaxDevices = 64;
+std::mutex g_noalloc_mu;
+unsigned char* g_noalloc_ptr[kMaxDevices];   // per device: address of ITS copy of `scratch` (null: not looked up yet)
+
+// Caller rays (origin, direction: 6 floats) -> a depth-0 path queue whose hit slots say "nothing hit yet".
+__global__ __launch_bounds__(256) void k_noalloc_pack(const float* __restrict__ rays, int n, float4* __restrict__ ray_o,
+                                                      float4* __restrict__ ray_d, float2* __restrict__ hit,
+                                                      unsigned* __restrict__ counts) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i == 0) counts[0] = (unsigned)n;
+    if (i >= n) return;
+    const float* r = rays + 6 * (size_t)i;
+    ray_o[i] = make_float4(r[0], r[1], r[2], __int_as_float(i));
+    ray_d[i] = make_float4(r[3], r[4], r[5], __int_as_float(PT_PRIM_MISS));
+    hit[i] = make_float2(PT_T_START, __int_as_float(PT_PRIM_MISS));
+}
+__global__ __launch_bounds__(256) void k_noalloc_unpack(const float2* __restrict__ hit, int n, int32_t* __restrict__ tri,
+                                                        float* __restrict__ t) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n) return;
+    const float2 h = hit[i];
+    t[i] = h.x;
+    tri[i] = __float_as_int(h.y);
+}
+}  // namespace
+
+gpt_status gpt_intersect_noalloc(gpt_scene* s, const float* d_rays, int n, int use_kdtree, int32_t* d_tri, float* d_t) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_tri || !d_t))) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n > GPT_NOALLOC_MAX_RAYS)
+        return fail(GPT_ERR_TOO_LARGE, "gpt_intersect_noalloc: more than GPT_NOALLOC_MAX_RAYS (16384) rays in one call");
+    if (use_kdtree && s->geom.n_tris > 0 && s->tree_depth + 2 > GPT_NOALLOC_SPILL_LEVELS)
+        return fail(GPT_ERR_TOO_LARGE, "gpt_intersect_noalloc: the kd-tree is deeper than the fixed traversal stack (62 levels)");
+    if (s->device < 0 || s->device >= kMaxDevices) return fail(GPT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    if (n == 0) return GPT_OK;
+    GPT_ON_DEVICE(s->device);
+    unsigned char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_noalloc_mu);
+        if (!g_noalloc_ptr[s->device]) {
+            // once per device, with that device current: where THIS GPU keeps its copy of the array
+            void* p = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_noalloc_ptr[s->device] = (unsigned char*)p;
+        }
+        base = g_noalloc_ptr[s->device];
+    }
+    float4* ray_o = (float4*)(base + GPT_NOALLOC_OFF_RAY_O);
+    float4* ray_d = (float4*)(base + GPT_NOALLOC_OFF_RAY_D);
+    float2* hit = (float2*)(base + GPT_NOALLOC_OFF_HIT);
+    unsigned* counts = (unsigned*)(base + GPT_NOALLOC_OFF_COUNTERS);
+    unsigned long long* stats = (unsigned long long*)(base + GPT_NOALLOC_OFF_STATS);
+    uint32_t* spill = (uint32_t*)(base + GPT_NOALLOC_OFF_SPILL);
+    // the array keeps the previous call's contents: queue heads, live counts and statistics start at zero
+    HIP_TRY(hipMemsetAsync(counts, 0, GPT_NOALLOC_COUNTER_BYTES + GPT_NOALLOC_STAT_BYTES, s->stream));
+    const int grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_noalloc_pack, dim3(grid), dim3(kBlock), 0, s->stream, d_rays, n, ray_o, ray_d, hit, counts);
+    if (s->geom.n_tris > 0)
+        gptk_intersect(s->stream, grid, &s->geom, use_kdtree ? 1 : 0, 0, 0, ray_o, ray_d, hit, counts, counts + GPT_MAX_DEPTH_SLOTS,
+                       stats, spill, (size_t)grid * kBlock, s->refill_below, s->leaf_min);
+    hipLaunchKernelGGL(k_noalloc_unpack, dim3(grid), dim3(kBlock), 0, s->stream, hit, n, d_tri, d_t);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return GPT_OK;
+}
+
 // ---- kd-tree builder through the C-ABI ----------------------------------------
 struct gpt_kdtree { gptkd::Tree tree; };
 

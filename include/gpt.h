@@ -263,6 +263,21 @@ gpt_status gpt_debug_primary_hits(gpt_scene* scene, const Camera* camera, int co
 gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int use_kdtree,
                                int32_t* tri, float* t);
 
+/* gpt_debug_intersect for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
+ * no counterpart in the reference.  `d_rays` (n x 6 floats), `d_tri` and `d_t` (n
+ * entries each) are DEVICE pointers on the scene's GPU; results are those of
+ * gpt_debug_intersect, bit for bit.  The call allocates and frees nothing: its ray
+ * queue, hit slots, counters and traversal-stack spill area live in one
+ * file-scope device array of 13.2 MiB that every GPU the library runs on holds
+ * until the process ends.  Limits (GPT_ERR_TOO_LARGE beyond them): at most
+ * GPT_NOALLOC_MAX_RAYS rays per call, kd-tree depth at most 62.  All calls on one
+ * GPU share that array: calls that overlap on one GPU race (serialise them);
+ * the call returns after its work has finished. */
+#define GPT_NOALLOC_MAX_RAYS 16384
+gpt_status gpt_intersect_noalloc(gpt_scene* scene, const float* d_rays, int n, int use_kdtree,
+                                 int32_t* d_tri, float* d_t);
+
 /* ------------------------------------------------------------------------- */
 /* kd-tree (host builder).  Flattened form, all arrays owned by the tree:      */
 /*   nodes      : n_nodes x 2 uint32   {w0, w1}                                */
