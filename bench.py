@@ -3,14 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one batch of 32 sample-per-pixel passes (--spp-per-step; a pass is
-launchKernel's unit of work) over the whole frame of the workload: passes are
-traced many at a time, so a handful of steps already runs at the rate of a long
-render.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) every rank renders its own K steps -- a disjoint range
-of pass counters, i.e. independently seeded samples -- and the float4
-accumulation images are sum-reduced once with RCCL at the end of the timed
-region; per-GPU work is fixed, so scaling is weak.
+A step is one frame of the workload at the metric's sample count: 1024
+sample-per-pixel passes (--spp-per-step; a pass is launchKernel's unit of
+work) over all pixels, traced 512 passes per kernel launch.
+
+N > 1: one process per GPU over RCCL.  Started without a launcher (no
+WORLD_SIZE in the environment) the script starts its N ranks itself, as a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, relays the
+child's JSON line and exits with its code; started by a launcher it is one of
+the ranks.  A world size other than --gpus is an error.
+  --scaling weak   (default) every rank renders its own K steps -- a disjoint
+                   range of pass counters, i.e. independently seeded samples;
+  --scaling strong the K x 1024 passes of the job are split across the ranks
+                   (rank r renders a contiguous 1/N of the pass counters);
+either way the float4 (r, g, b, passes) images are sum-reduced once with RCCL at
+the end of the timed region.
 
 Workload (BASELINE.json `metric`): the reference scene as launchKernel would
 see it with its mesh path enabled on a heavy cow: the 14 default spheres,
@@ -22,11 +29,13 @@ the timed region starts.
 
 Rank 0 prints one JSON line; `roofline` describes the dominant kernel
 (k_intersect_kd, the kd-tree traversal) and `cpu_baseline` the CPU oracle timed on
-a bounded sample of the same workload.
+a bounded sample of the same workload (outside the timed region).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -98,12 +107,13 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=32, help="sample-per-pixel passes per step")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=1024, help="sample-per-pixel passes per step")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--workload", default="cow_heavy")
     ap.add_argument("--subdiv", type=int, default=4)
     ap.add_argument("--width", type=int, default=1920)
@@ -115,25 +125,125 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch and the sharding without a GPU: gloo ranks, no rendering (CPU tests)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start the N ranks as a fresh child process tree (nothing in
+    this process has touched the GPU), relay the child's output, return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0:
+        if len(lines) != 1:
+            print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+            return 1
+        if json.loads(lines[0]).get("n_gpus") != args.gpus:
+            print("bench.py: the ranks report n_gpus=%s, not %d" % (json.loads(lines[0]).get("n_gpus"), args.gpus), file=sys.stderr)
+            return 1
+        print(lines[0])
+    return proc.returncode
+
+
+def rank_passes(args, rank, world):
+    """(warm-up range, timed range) of pass counters of `rank`; ranges of different ranks never overlap."""
+    from gpupathtracer_amd import sharding
+    Kp, Wp = args.steps * args.spp_per_step, args.warmup * args.spp_per_step
+    if args.scaling == "strong":
+        # the job's Kp passes are split; warm-up counters lie beyond them
+        tb, te = sharding.pass_range(Kp, rank, world)
+        wb, we = sharding.pass_range(Wp, rank, world)
+        return (Kp + wb, Kp + we), (tb, te)
+    base, _ = sharding.weak_range(Kp + Wp, rank)
+    return (base, base + Wp), (base + Wp, base + Wp + Kp)
+
+
+def dry_run(args, rank, world):
+    """The launch path without a GPU: rendezvous over gloo, the ranks' pass ranges, one sum-reduce."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    (wb, we), (tb, te) = rank_passes(args, rank, world)
+    t = torch.tensor([float(te - tb), float(tb), float(te), 1.0], dtype=torch.float64)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(gathered, t)
+    else:
+        gathered = [t]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "scaling": args.scaling, "passes": [int(g[0]) for g in gathered],
+                          "ranges": [[int(g[1]), int(g[2])] for g in gathered]}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def load_traffic(path, match):
+    """HBM-side bytes per path-bounce of k_intersect_kd from a stored rocprofv3 --pmc collection --
+    only when that collection was made on the configuration of this run."""
+    if not os.path.exists(path):
+        return None, "no stored counters"
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None, "unreadable " + os.path.basename(path)
+    cfg = tj.get("config")
+    if cfg != match:
+        return None, "stored counters are for another configuration (%s)" % json.dumps(cfg)
+    if not tj.get("k_intersect_hbm_bytes_per_launch") or not tj.get("path_bounces_per_launch"):
+        return None, "incomplete " + os.path.basename(path)
+    return tj["k_intersect_hbm_bytes_per_launch"] / tj["path_bounces_per_launch"], \
+        "stored: %s (%s), not measured in this run" % (os.path.relpath(path, ROOT), tj.get("source", "rocprofv3 --pmc"))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args, argv))          # before anything imports torch or touches the GPU
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
     from gpupathtracer_amd import api, sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d has no GPU: %d visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     # GPT_FORCE_DIST=1 exercises the RCCL path with a single rank (one-GPU boxes)
     distributed = world > 1 or os.environ.get("GPT_FORCE_DIST") == "1"
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     TRIS[0] = args.tris
@@ -143,7 +253,6 @@ def main():
     cam = api.default_camera(args.width, args.height)
     n_pix = args.width * args.height
     K, W = args.steps, args.warmup
-    Kp, Wp = K * args.spp_per_step, W * args.spp_per_step     # passes
 
     params = api.render_params(max_depth=args.depth, row_stride_is_width=1, use_kdtree=1,
                                passes_in_flight=args.batch, **({"kd_small_threshold": args.kd_small} if args.kd_small > 0 else {}))
@@ -158,42 +267,46 @@ def main():
         scene.sync()
         torch.cuda.synchronize()
 
-    # rank r owns pass counters [r*(Kp+Wp), (r+1)*(Kp+Wp)): disjoint, independently seeded samples
-    base, _ = sharding.weak_range(Kp + Wp, rank)
+    (wb, we), (tb, te) = rank_passes(args, rank, world)
+    my_passes = te - tb
 
     # ---- untimed: kd work per path-bounce (instrumented kernel), then warm-up ----
     scene.set_profiling(time_kernels=False, count_kd_work=True)
-    scene.render_range(cam, base, base + 1)
+    scene.render_range(cam, tb, tb + 1)
     st = scene.stats()
     pb1 = max(1, st["path_bounces"])
     nodes_per_pb = st["kd_nodes_visited"] / pb1
     tris_per_pb = st["kd_tris_tested"] / pb1
     hit_frac = st["hits"] / pb1
     scene.set_profiling(time_kernels=False, count_kd_work=False)
-    scene.render_range(cam, base, base + Wp)
+    scene.render_range(cam, wb, we)
     scene.reset(n_pix)
     scene.set_profiling(time_kernels=True, count_kd_work=False)
 
     image = sharding.scene_image_tensor(scene, torch.device("cuda", local_rank))
 
-    # ---- timed region: exactly K steps (Kp passes) per rank + the sum-reduce of the images ----
+    # ---- timed region: exactly K steps + the sum-reduce of the images ----
     barrier()
     t0 = time.perf_counter()
-    scene.render_range(cam, base + Wp, base + Wp + Kp, sync=True)
-    sharding.sum_images(image)
+    scene.render_range(cam, tb, te, sync=True)
+    sharding.sum_images(image, force=distributed)
     barrier()
     elapsed = time.perf_counter() - t0
 
     st = scene.stats()
-    t = torch.tensor([elapsed, float(st["path_bounces"])], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(st["path_bounces"]), float(my_passes)], dtype=torch.float64, device="cuda")
     if distributed:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, total_pb = float(tmax[0]), float(tsum[1])
+        elapsed_max, total_pb, total_passes = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2])))
     else:
-        elapsed_max, total_pb = elapsed, float(st["path_bounces"])
+        elapsed_max, total_pb, total_passes = elapsed, float(st["path_bounces"]), my_passes
+    # every pass of the job is in the reduced image exactly once (its 4th channel counts them)
+    passes_in_image = int(round(float(image[3].item())))
+    if passes_in_image != total_passes:
+        raise SystemExit("reduced image holds %d passes, the ranks rendered %d" % (passes_in_image, total_passes))
 
     if rank == 0:
         n_spheres = int(spheres.size)
@@ -208,6 +321,8 @@ def main():
         launches = max(1, st["trace_launches"])
         pb_per_launch = st["path_bounces"] / launches
         trace_share = st["device_ms_trace"] / max(1e-9, st["device_ms_total"])
+        info = scene.info()
+        batch = info.pop("passes_in_flight")
         if trace_share >= 0.5:
             kernel, kernel_bytes = "k_intersect_kd<false>", kd_bytes_per_pb
             avg_launch_s = st["device_ms_trace"] / 1e3 / launches
@@ -217,20 +332,45 @@ def main():
             avg_launch_s = (st["device_ms_total"] - st["device_ms_trace"]) / 1e3 / launches
         achieved = kernel_bytes * pb_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         pass_level = bytes_per_pb * st["path_bounces"] / (st["device_ms_total"] / 1e3) / 1e9 if st["device_ms_total"] > 0 else 0.0
-        traffic = None
-        if os.path.exists(args.traffic_file):
-            try:
-                tj = json.load(open(args.traffic_file))
-                traffic = tj.get("k_intersect_hbm_bytes_per_launch")
-                # the counters were collected at one batch size: scale to this run's launch
-                ref_pb = tj.get("path_bounces_per_launch")
-                if traffic is not None and ref_pb:
-                    traffic = traffic * pb_per_launch / ref_pb
-            except Exception:
-                traffic = None
-        if kernel != "k_intersect_kd<false>":
-            traffic = None
-        info = scene.info()
+        traffic, traffic_source = None, "not collected for this kernel"
+        # what a stored counter collection must have been made on to speak for this run
+        counter_config = {"workload": args.workload, "subdiv": args.subdiv if args.workload == "cow_heavy" else None,
+                          "tris": 0 if polys is None else int(polys.size), "width": args.width, "height": args.height,
+                          "depth": args.depth, "passes_per_launch": batch, "kd": info}
+        if kernel == "k_intersect_kd<false>":
+            per_pb, traffic_source = load_traffic(args.traffic_file, counter_config)
+            if per_pb is not None:
+                traffic = per_pb * pb_per_launch
+        # A workload whose algorithmic bytes exceed what HBM could deliver in the measured time is served
+        # from the caches: its bound is the vector ALU, and an HBM fraction would say nothing.
+        cache_resident = achieved > HBM_PEAK_GBS
+        roofline = {
+            "kernel": kernel,
+            "bound": "valu" if cache_resident else "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": None if cache_resident else achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "counter_config": counter_config,
+            # measured HBM-side bytes over the kernel's time over the peak (needs stored counters of this configuration)
+            "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
+            "algorithmic_gbps": achieved,
+            "bytes_per_path_bounce": kernel_bytes,
+            "pass_level": {"bytes_per_path_bounce": bytes_per_pb, "algorithmic_gbps": pass_level,
+                           "note": "whole path-bounce (all kernels, sphere reads included) over whole device time; not an HBM fraction"},
+            "kd_nodes_per_path_bounce": nodes_per_pb,
+            "tris_per_path_bounce": tris_per_pb,
+            "hit_fraction": hit_frac,
+            "avg_launch_ms": avg_launch_s * 1e3,
+            "launches": launches,
+            "path_bounces_per_launch": pb_per_launch,
+            "intersect_share_of_pass": trace_share,
+        }
+        if cache_resident:
+            roofline["note"] = ("algorithmic bytes exceed what HBM could deliver in that time: the scene is cache resident and "
+                                "the kernel VALU-bound; see profiles/ for its VALU utilisation")
         out = {
             "metric": "Mpath-bounces/s",
             "value": total_pb / elapsed_max / 1e6,
@@ -240,12 +380,13 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed_max / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "ms_per_pass": elapsed_max / Kp * 1e3,
-            "spp_per_s": world * Kp / elapsed_max,
+            "ms_per_pass": elapsed_max / max(1, my_passes) * 1e3,
+            "spp_per_s": total_passes / elapsed_max,
+            "timed_region_s": elapsed_max,
             "config": {
                 "workload": "%s: %s (%d triangles) + the reference's 14 spheres, "
                             "ground and sky; default orbit camera %dx%d, depth %d, %d spp per step, kd-tree"
@@ -254,33 +395,14 @@ def main():
                                 "spheres": "no mesh", "diamond_coil": "glass diamond + marble coil",
                                 "soup": "uniform random small white triangles"}[args.workload],
                                0 if polys is None else polys.size, args.width, args.height, args.depth, args.spp_per_step),
-                "passes_per_gpu": Kp,
-                "passes_per_launch": info.pop("passes_in_flight"),
-                "parallelism": "spp-sharded x%d, one RCCL sum-reduce of the float4 image" % world,
-                "bounces_per_path": st["path_bounces"] / max(1, Kp * n_pix),
+                "passes_total": total_passes,
+                "passes_per_gpu": my_passes,
+                "passes_per_launch": batch,
+                "parallelism": "spp-sharded x%d (%s), one RCCL sum-reduce of the float4 image" % (world, args.scaling),
+                "bounces_per_path": st["path_bounces"] / max(1, my_passes * n_pix),
                 "kd": dict(info, build_and_upload_s=round(t_build, 2)),
             },
-            "roofline": {
-                "kernel": kernel,
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "bytes_per_path_bounce": kernel_bytes,
-                "pass_level": {"bytes_per_path_bounce": bytes_per_pb, "achieved": pass_level,
-                               "frac": pass_level / HBM_PEAK_GBS},
-                "kd_nodes_per_path_bounce": nodes_per_pb,
-                "tris_per_path_bounce": tris_per_pb,
-                "hit_fraction": hit_frac,
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "launches": launches,
-                "path_bounces_per_launch": pb_per_launch,
-                "intersect_share_of_pass": trace_share,
-                **({"note": "algorithmic bytes exceed what HBM could deliver in that time: the scene is cache resident"}
-                   if achieved > HBM_PEAK_GBS else {}),
-            },
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spheres, polys if polys is not None else None, cam, args.depth)

@@ -47,6 +47,7 @@ SYMBOLS = {
     "gpt_accum_device_ptr": (_I, [_V, c_void_pp, ctypes.POINTER(ctypes.c_size_t)]),
     "gpt_accum_download": (_I, [_V, _V, ctypes.POINTER(_I)]),
     "gpt_accum_upload": (_I, [_V, _V, _I]),
+    "gpt_accum_allreduce": (_I, [c_void_pp, _I]),
     "gpt_get_stats": (_I, [_V, ctypes.POINTER(GptStats)]),
     "gpt_scene_set_profiling": (_I, [_V, _I, _I]),
     "gpt_scene_info": (_I, [_V, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),

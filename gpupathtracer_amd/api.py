@@ -164,6 +164,12 @@ class Scene:
         return tri, t
 
 
+def accum_allreduce(scenes):
+    """gpt_accum_allreduce: one RCCL sum of the scenes' accumulated images (one scene per GPU)."""
+    arr = (ctypes.c_void_p * len(scenes))(*[sc._h for sc in scenes])
+    _check(_lib.lib().gpt_accum_allreduce(ctypes.cast(arr, _lib.c_void_pp), len(scenes)))
+
+
 NOALLOC_MAX_RAYS = 16384
 
 

@@ -2,6 +2,7 @@
 // pass orchestration on one HIP stream, statistics, and the reference-compatible
 // launchKernel entry point (path_tracer_kernel.cu:760-882).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -807,6 +808,95 @@ gpt_status gpt_debug_intersect(gpt_scene* s, const float* rays, int n, int use_k
         }
     } while (0);
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_cnt); (void)hipFree(d_st);
+    return st;
+}
+
+// ---- multi-GPU: one RCCL sum of the accumulated images ---------------------------
+// Samples-per-pixel shard across GPUs: each GPU renders its own range of pass counters into its own
+// scene, then the float4 (r, g, b, passes) images are summed once over xGMI.  RCCL is loaded on first
+// use (the library has no link-time dependency on it; a process that already holds RCCL, such as one
+// that imported torch, shares that copy).
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool ok = false;
+};
+const int kNcclFloat = 7, kNcclSum = 0;   // rccl.h: ncclFloat32, ncclSum
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("cannot load librccl: ") + dlerror(); return; }
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.handle, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.AllReduce && r.GetErrorString;
+        if (!r.ok) r.error = "librccl lacks an expected symbol";
+    });
+    return &r;
+}
+
+// communicators are kept per device list: creating them costs far more than a reduce
+std::mutex g_comm_mu;
+std::map<std::vector<int>, std::vector<void*>> g_comms;
+}  // namespace
+
+gpt_status gpt_accum_allreduce(gpt_scene* const* scenes, int n) {
+    if (!scenes || n <= 0) return fail(GPT_ERR_INVALID_ARGUMENT, "no scenes");
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) {
+        if (!scenes[i] || !scenes[i]->d_image) return fail(GPT_ERR_INVALID_ARGUMENT, "scene without an image (call gpt_scene_reset first)");
+        if (scenes[i]->numPixels != scenes[0]->numPixels) return fail(GPT_ERR_INVALID_ARGUMENT, "scenes differ in their pixel count");
+        for (int d : devs)
+            if (d == scenes[i]->device) return fail(GPT_ERR_INVALID_ARGUMENT, "two scenes on one device: each GPU takes part once");
+        devs.push_back(scenes[i]->device);
+    }
+    Rccl& R = *rccl();
+    if (!R.ok) return fail(GPT_ERR_HIP, R.error);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    std::vector<void*>& comms = g_comms[devs];
+    gpt_status st = GPT_OK;
+    do {
+        if (comms.empty()) {
+            comms.assign((size_t)n, nullptr);
+            const int rc = R.CommInitAll(comms.data(), n, devs.data());
+            if (rc != 0) { comms.clear(); st = fail(GPT_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(rc)); break; }
+        }
+        // every scene's reduce is queued on that scene's own stream, i.e. behind its rendering
+        int rc = R.GroupStart();
+        for (int i = 0; i < n && rc == 0; i++) {
+            if (hipSetDevice(devs[(size_t)i]) != hipSuccess) { rc = -1; break; }
+            rc = R.AllReduce(scenes[i]->d_image, scenes[i]->d_image, (size_t)scenes[i]->numPixels * 4, kNcclFloat, kNcclSum,
+                             comms[(size_t)i], scenes[i]->stream);
+        }
+        const int rc_end = R.GroupEnd();
+        if (rc == 0) rc = rc_end;
+        if (rc != 0) { st = fail(GPT_ERR_HIP, std::string("ncclAllReduce: ") + (rc > 0 ? R.GetErrorString(rc) : "hipSetDevice failed")); break; }
+        for (int i = 0; i < n; i++) {
+            if (hipSetDevice(devs[(size_t)i]) != hipSuccess || hipStreamSynchronize(scenes[i]->stream) != hipSuccess) {
+                st = fail(GPT_ERR_HIP, "waiting for the reduce failed");
+                break;
+            }
+        }
+    } while (0);
+    if (prev >= 0) (void)hipSetDevice(prev);
     return st;
 }
 

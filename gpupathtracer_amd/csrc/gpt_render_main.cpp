@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpt.h"
@@ -16,11 +17,13 @@ static void usage() {
             "usage: gpt_render [--width W] [--height H] [--spp N] [--depth D] [--out image.ppm] [--pfm image.pfm] [--exr image.exr]\n"
             "                  [--obj mesh.obj [--material NAME] [--scale S] [--translate X Y Z]] [--no-spheres]\n"
             "                  [--yaw R] [--pitch R] [--radius R] [--aperture R] [--fovx DEG] [--center X Y Z]\n"
-            "                  [--brute-force] [--device N]\n");
+            "                  [--brute-force] [--device N] [--gpus N]\n"
+            "  --gpus N: the spp passes are split across devices 0..N-1 (one host thread and one scene per GPU,\n"
+            "            disjoint ranges of pass counters) and the images summed with one RCCL all-reduce\n");
 }
 
 int main(int argc, char** argv) {
-    int width = 512, height = 512, spp = 64, depth = 30, device = 0;   // display.cpp:33-34, MAX_TRACE_DEPTH
+    int width = 512, height = 512, spp = 64, depth = 30, device = 0, gpus = 0;   // display.cpp:33-34, MAX_TRACE_DEPTH
     std::string out = "render.ppm", pfm, exr, obj, material = "glass";
     float scale = 1, tr[3] = {0, 0, 0};
     float yaw = 0, pitch = 0.3f, radius = 4, aperture = 0.04f, fovx = 45, center[3] = {0, 0, 0};
@@ -33,6 +36,7 @@ int main(int argc, char** argv) {
         else if (a == "--spp") { need(1); spp = atoi(argv[++i]); }
         else if (a == "--depth") { need(1); depth = atoi(argv[++i]); }
         else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--pfm") { need(1); pfm = argv[++i]; }
         else if (a == "--exr") { need(1); exr = argv[++i]; }
@@ -76,16 +80,34 @@ int main(int argc, char** argv) {
     Camera cam;
     gpt_orbit_camera((float)width, (float)height, fovx, yaw, pitch, radius, aperture, center, &cam);
 
-    gpt_scene* scene = nullptr;
+    // One scene per GPU.  Without --gpus: a single scene on --device.  With --gpus N: device g renders the
+    // contiguous g-th share of the pass counters 0..spp-1 (every sample is a function of its counter alone,
+    // so the union is the single-GPU render's sample set), then one RCCL sum makes every image the total.
+    const int n_dev = gpus > 0 ? gpus : 1;
+    std::vector<gpt_scene*> scenes((size_t)n_dev, nullptr);
+    std::vector<std::string> errors((size_t)n_dev);
+    auto on_all = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n_dev; g++) th.emplace_back([&, g]() { if (fn(g) != GPT_OK) errors[(size_t)g] = gpt_last_error(); });
+        for (auto& t : th) t.join();
+        for (int g = 0; g < n_dev; g++)
+            if (!errors[(size_t)g].empty()) { fprintf(stderr, "GPU %d: %s\n", g, errors[(size_t)g].c_str()); return false; }
+        return true;
+    };
     auto t0 = std::chrono::steady_clock::now();
-    if (gpt_scene_create(spheres.data(), (int)spheres.size(), polys, numPolys, &rp, device, &scene) != GPT_OK ||
-        gpt_scene_reset(scene, width * height) != GPT_OK) {
-        fprintf(stderr, "%s\n", gpt_last_error());
-        return 1;
-    }
+    if (!on_all([&](int g) {
+            gpt_status st = gpt_scene_create(spheres.data(), (int)spheres.size(), polys, numPolys, &rp, gpus > 0 ? g : device, &scenes[(size_t)g]);
+            return st != GPT_OK ? st : gpt_scene_reset(scenes[(size_t)g], width * height);
+        })) return 1;
     auto t1 = std::chrono::steady_clock::now();
-    if (gpt_render_range(scene, &cam, 0, spp, 1) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+    if (!on_all([&](int g) {
+            const int base = spp / n_dev, extra = spp % n_dev;
+            const int begin = g * base + (g < extra ? g : extra), end = begin + base + (g < extra ? 1 : 0);
+            return gpt_render_range(scenes[(size_t)g], &cam, begin, end, 1);
+        })) return 1;
+    if (gpus > 0 && gpt_accum_allreduce(scenes.data(), n_dev) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     auto t2 = std::chrono::steady_clock::now();
+    gpt_scene* scene = scenes[0];
     std::vector<float> img((size_t)width * height * 3);
     int passes = 0;
     gpt_stats st;
@@ -93,15 +115,21 @@ int main(int argc, char** argv) {
         fprintf(stderr, "%s\n", gpt_last_error());
         return 1;
     }
+    for (int g = 1; g < n_dev; g++) {
+        gpt_stats sg;
+        if (gpt_get_stats(scenes[(size_t)g], &sg) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
+        st.path_bounces += sg.path_bounces;
+    }
     double sec = std::chrono::duration<double>(t2 - t1).count();
     // the reference's overlay: iterations, seconds, FPS (display.cpp:232-250)
     printf("Iterations: %d\nSeconds: %.3f\nFPS: %.2f\n", passes, sec, passes / (sec > 0 ? sec : 1));
+    if (gpus > 0) printf("GPUs: %d (spp-sharded, one RCCL sum)\n", n_dev);
     printf("Scene upload + kd-tree: %.3f s; %.1f Mpath-bounces/s\n", std::chrono::duration<double>(t1 - t0).count(),
            (double)st.path_bounces / (sec > 0 ? sec : 1) / 1e6);
     if (gpt_write_ppm(out.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     if (!pfm.empty() && gpt_write_pfm(pfm.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     if (!exr.empty() && gpt_write_exr(exr.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
-    gpt_scene_destroy(scene);
+    for (gpt_scene* sc : scenes) gpt_scene_destroy(sc);
     gpt_free(polys);
     return 0;
 }

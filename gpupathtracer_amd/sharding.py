@@ -25,9 +25,11 @@ def weak_range(passes_per_rank, rank, offset=0):
     return begin, begin + int(passes_per_rank)
 
 
-def sum_images(image, group=None):
-    """In-place sum of the per-rank (r, g, b, passes) images over all ranks."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def sum_images(image, group=None, force=False):
+    """In-place sum of the per-rank (r, g, b, passes) images over all ranks.  A group of one rank has
+    nothing to add and is skipped unless `force` asks for the collective anyway (to exercise the RCCL
+    path on a one-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
     return image
 

@@ -221,6 +221,15 @@ gpt_status gpt_accum_download(gpt_scene* scene, float* host_rgb, int* out_passes
 /* Replace the accumulated image (e.g. with the RCCL-reduced one). */
 gpt_status gpt_accum_upload(gpt_scene* scene, const float* host_rgb, int passes);
 
+/* Multi-GPU (no counterpart in the reference, which drives one GPU): samples per
+ * pixel shard across the GPUs of a node -- scene i, on its own device, renders its
+ * own range of pass counters -- and this call sums the n accumulated images
+ * (r, g, b and the pass count) with ONE RCCL all-reduce over xGMI, queued on each
+ * scene's stream behind its rendering; it returns when every scene holds the sum.
+ * The scenes must be on n different devices and have the same pixel count.
+ * RCCL (librccl.so) is loaded on first use. */
+gpt_status gpt_accum_allreduce(gpt_scene* const* scenes, int n);
+
 /* Work counters since the last gpt_scene_reset. */
 typedef struct gpt_stats {
     uint64_t path_bounces;        /* sum over passes and depths of live paths  */

@@ -84,3 +84,38 @@ def test_two_rank_sum_equals_single_process_sum(tmp_path):
 def test_sum_images_is_a_no_op_without_a_process_group():
     t = torch.arange(8, dtype=torch.float32)
     assert torch.equal(sharding.sum_images(t.clone()), t)
+
+
+def _run_bench(args, env_extra=None):
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                         text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out.returncode, [json.loads(ln) for ln in lines], out.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher starts two ranks itself (a fresh child under
+    torch.distributed.run); the dry run rehearses rendezvous and sharding over gloo without a GPU."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spp-per-step", "7", "--dry-run"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["scaling"] == "weak"
+    (b0, e0), (b1, e1) = lines[0]["ranges"]
+    assert e0 - b0 == e1 - b1 == 21 and (e0 <= b1 or e1 <= b0)       # weak: 3 steps x 7 passes each, disjoint counters
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--spp-per-step", "7", "--dry-run",
+                                 "--scaling", "strong"])
+    assert rc == 0, err
+    assert lines[0]["ranges"] == [[0, 11], [11, 21]] and lines[0]["scaling"] == "strong"   # 21 passes split
+
+
+def test_bench_rejects_a_world_size_other_than_gpus():
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "--gpus 2" in err
+    rc, lines, err = _run_bench(["--gpus", "1", "--dry-run"])
+    assert rc == 0 and lines[0]["n_gpus"] == 1

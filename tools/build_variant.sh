@@ -9,6 +9,6 @@ FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-ma
 /opt/rocm/bin/hipcc $FLAGS -c -o $tmp/k.o gpt_kernels.hip
 /opt/rocm/bin/hipcc $FLAGS -c -o $tmp/kb.o kdtree_build_gpu.hip &
 for f in gpt_api gpt_host_io kdtree_build; do /opt/rocm/bin/hipcc $FLAGS -x hip -c -o $tmp/$f.o $f.cpp & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpt_hip_$name.so $tmp/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpt_hip_$name.so $tmp/*.o -ldl
 rm -rf $tmp
 echo built libgpt_hip_$name.so

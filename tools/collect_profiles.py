@@ -46,9 +46,11 @@ derived = {
 }
 # the bench line of the traced run (its JSON is in the pass's log) tells how many path-bounces a launch held
 pb_per_launch = None
+counter_config = None
 for line in open(os.path.join(src, "trace.log"), errors="replace"):
     if line.startswith("{"):
         pb_per_launch = json.loads(line)["roofline"]["path_bounces_per_launch"]
+        counter_config = json.loads(line)["roofline"]["counter_config"]
         shutil.copy(os.path.join(src, "trace.log"), os.path.join(out, tag + "_bench_under_trace.log"))
 derived["path_bounces_per_launch"] = pb_per_launch
 d["derived_k_intersect_kd"] = derived
@@ -56,6 +58,8 @@ json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
 json.dump({
     "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
     "path_bounces_per_launch": pb_per_launch,
+    # bench.py reports these counters only for a run of this very configuration
+    "config": counter_config,
     "how": "rocprofv3 --pmc, separate passes: sum(TCC_EA0_RDREQ_{32,64,128}B_sum x request size) + WRITE_SIZE*1024, "
            "divided by the kernel's dispatches; bench.py --spp-per-step 1 --steps 512 --warmup 0 (8 launches of 512 passes)",
     "source": tag + "_pmc_summary.json",

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmcx_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 256 --warmup 0 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --spp-per-step 1 --steps 256 --warmup 0 --no-cpu-baseline $*"
 run() {
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
