@@ -164,6 +164,14 @@ class Scene:
         return tri, t
 
 
+def rng_uniforms(seeds, n_draws, device=0):
+    """gpt_debug_rng_uniforms: the device's uniform streams, [len(seeds), n_draws] float32."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    out = np.empty((seeds.size, int(n_draws)), dtype=np.float32)
+    _check(_lib.lib().gpt_debug_rng_uniforms(int(device), _ptr(seeds), seeds.size, int(n_draws), _ptr(out)))
+    return out
+
+
 def accum_allreduce(scenes):
     """gpt_accum_allreduce: one RCCL sum of the scenes' accumulated images (one scene per GPU)."""
     arr = (ctypes.c_void_p * len(scenes))(*[sc._h for sc in scenes])

@@ -45,6 +45,7 @@ void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, cons
                          unsigned long long* out);
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
+void gptk_rng_uniforms(hipStream_t s, const uint32_t* seeds, int n_seeds, int n_draws, float* out);
 }
 
 namespace {
@@ -746,6 +747,31 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
         memcpy(&prim[pixel], &h[2 * (size_t)i + 1], 4);
     }
     return GPT_OK;
+}
+
+// The device's uniform streams for the given seeds (parity of the random numbers themselves).
+gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
+    if (!seeds || !out || n_seeds <= 0 || n_draws <= 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GPT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(GPT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    GPT_ON_DEVICE(device);
+    uint32_t* d_seeds = nullptr;
+    float* d_out = nullptr;
+    const size_t n_out = (size_t)n_seeds * (size_t)n_draws;
+    gpt_status st = GPT_OK;
+    if (hipMalloc((void**)&d_seeds, (size_t)n_seeds * 4) != hipSuccess || hipMalloc((void**)&d_out, n_out * 4) != hipSuccess) {
+        st = fail(GPT_ERR_OUT_OF_MEMORY, "rng buffers");
+    } else if (hipMemcpy(d_seeds, seeds, (size_t)n_seeds * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        st = fail(GPT_ERR_HIP, "rng upload");
+    } else {
+        gptk_rng_uniforms(nullptr, d_seeds, n_seeds, n_draws, d_out);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out, n_out * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            st = fail(GPT_ERR_HIP, "rng kernel");
+    }
+    (void)hipFree(d_seeds);
+    (void)hipFree(d_out);
+    return st;
 }
 
 // Closest triangle for caller-supplied rays, through the SAME intersect kernels a render pass

@@ -779,6 +779,18 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_extract_pass(int numPixels, int n
     }
 }
 
+// The device's random-number stream, for parity checks: out[s * n_draws + k] = k-th uniform of an
+// engine seeded with seeds[s] (thrust::default_random_engine + uniform_real_distribution<float>(0,1)
+// as the reference uses them, path_tracer_kernel.cu:139-142, 492-493).
+__global__ __launch_bounds__(GPT_BLOCK) void k_rng_uniforms(const uint32_t* __restrict__ seeds, int n_seeds, int n_draws,
+                                                            float* __restrict__ out) {
+    const int s = (int)(blockIdx.x * GPT_BLOCK + threadIdx.x);
+    if (s >= n_seeds) return;
+    Rng rng;
+    rng.seed(seeds[s]);
+    for (int k = 0; k < n_draws; k++) out[(size_t)s * (size_t)n_draws + (size_t)k] = rng.uniform();
+}
+
 // ---------------------------------------------------------------------------
 // Instrumentation and the scene checksum
 // ---------------------------------------------------------------------------
@@ -865,6 +877,11 @@ void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, cons
     if (n_refs == 0) return;
     hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n_refs + GPT_BLOCK - 1) / GPT_BLOCK)), dim3(GPT_BLOCK), 0, s, n_refs, refs,
                        dst, tris, out);
+}
+
+void gptk_rng_uniforms(hipStream_t s, const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
+    hipLaunchKernelGGL(k_rng_uniforms, dim3((unsigned)((n_seeds + GPT_BLOCK - 1) / GPT_BLOCK)), dim3(GPT_BLOCK), 0, s, seeds, n_seeds,
+                       n_draws, out);
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {

@@ -272,6 +272,11 @@ gpt_status gpt_debug_primary_hits(gpt_scene* scene, const Camera* camera, int co
 gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int use_kdtree,
                                int32_t* tri, float* t);
 
+/* The device's random numbers (debug/parity): out[s * n_draws + k] = k-th uniform of an engine
+ * seeded with seeds[s] -- thrust::default_random_engine + uniform_real_distribution<float>(0,1)
+ * as used at path_tracer_kernel.cu:139-142, 492-493.  Host arrays. */
+gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds, int n_draws, float* out);
+
 /* gpt_debug_intersect for callers that cannot allocate device memory: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
  * no counterpart in the reference.  `d_rays` (n x 6 floats), `d_tri` and `d_t` (n

@@ -6,14 +6,15 @@
  * checker in tests/, in __graft_entry__.smoke() and as bench.py's
  * cpu_baseline leg.  Nothing in the shipped library links or calls it.
  *
- * Pinning status: the reference ships no tests, golden images or known-answer
- * vectors, and its launcher cannot be built in this image (it needs the CUDA
- * toolkit headers and Thrust; writing stand-ins for them is not done).  The
- * restatement is therefore pinned by (1) the Thrust documentation KAT for
- * minstd_rand (10000th draw == 399268537), (2) the randhash / uniform values
- * and the render statistics recorded from a host run of the reference kernel
- * text during the survey of the reference (see tests/golden/README.md), and
- * otherwise "parity unpinned" by the reference's own fixtures (none exist).
+ * Pinning status: PARITY UNPINNED for the kernel path.  The reference ships no
+ * tests, golden images or known-answer vectors, and its launcher cannot be built
+ * in this image (it needs the CUDA toolkit headers; stand-ins are not written).
+ * Pinned from outside this repository are only (1) the random numbers: the
+ * generator below reproduces, bit for bit, tests/golden/thrust_rng.npz -- 64 seeds
+ * x 4096 uniforms drawn from the real Thrust classes of the image's rocThrust --
+ * and Thrust's documented 10000th minstd_rand value 399268537; (2) the mesh
+ * inputs, tests/golden/obj_*.npz, produced by the reference's own OBJ loader.
+ * Everything else rests on this restatement alone.
  *
  * Arithmetic follows what a host C++ compiler makes of the reference text:
  * double sub-expressions where a double literal or pow(float,int) appears,

@@ -193,6 +193,15 @@ int64_t hh_render_pass(void* tree_or_null, int numPolys, const Poly* polys, int 
     return total;
 }
 
+// pt::Rng (the generator the kernels use), host build: n_draws uniforms per seed
+void hh_rng_uniforms(const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
+    for (int s = 0; s < n_seeds; s++) {
+        pt::Rng rng;
+        rng.seed(seeds[s]);
+        for (int k = 0; k < n_draws; k++) out[(size_t)s * n_draws + k] = rng.uniform();
+    }
+}
+
 void hh_camera_rays(const int32_t* pixel_ids, int n, int counter, const Camera* cam, int row_stride_is_width, float* out) {
     CamPre cp = camera_precompute(v3(cam->position.x, cam->position.y, cam->position.z),
                                   v3(cam->view.x, cam->view.y, cam->view.z),

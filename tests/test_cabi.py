@@ -179,35 +179,6 @@ def test_obj_loader_errors(tmp_path):
         api.obj_load(dbl)
 
 
-# pins recorded from the reference's own loader for its bundled meshes
-REF_MESH_PINS = {
-    "box": (12, (-0.8, -0.8, -0.8, 0.8, 0.8, 0.8)),
-    "cow": (5804, (-0.792737, -0.038824, -0.303377, 1.06952, 1.10178, 0.303377)),
-    "diamond": (110, (-0.784783, 1.5719, -2.66099, 0.561428, 2.91262, -0.976664)),
-    "coil": (492, (-0.916164, 6.13932, -1.13891, 2.74781, 10.6133, 2.67188)),
-}
-
-
-@pytest.mark.parametrize("name", sorted(REF_MESH_PINS))
-def test_reference_meshes_load_with_recorded_counts(reference_root, name):
-    polys, bbox = api.obj_load(os.path.join(reference_root, name + ".obj"))
-    faces, want_bbox = REF_MESH_PINS[name]
-    assert polys.size == faces
-    assert np.allclose(bbox, want_bbox, rtol=0, atol=1e-5)
-    v, n, bb = objref.triangles(os.path.join(reference_root, name + ".obj"))
-    got_v = np.concatenate([polys["p0"], polys["p1"], polys["p2"]], axis=1)
-    assert np.array_equal(got_v, v) and np.array_equal(polys["n"], n)
-    av, an = meshes.load_asset(name)               # the bundled asset is exactly that data
-    assert np.array_equal(av, v) and np.array_equal(an, n)
-
-
-def test_cow_first_face_pin(reference_root):
-    polys, _ = api.obj_load(os.path.join(reference_root, "cow.obj"))
-    # face 0 is "f 3//1 4//2 2//3": p0 = vertex 3, normal = normal 1
-    assert np.allclose(polys["p0"][0], [0.429791987, 0.470970988, -0.149976999], atol=1e-7)
-    assert np.allclose(polys["n"][0], [0.442214012, -0.167945996, -0.881044984], atol=1e-7)
-
-
 def test_scene_create_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

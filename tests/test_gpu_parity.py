@@ -36,6 +36,16 @@ def check_pass(got, ref, flip_fraction=FLIP_FRACTION):
     return bad
 
 
+def test_device_rng_equals_thrust():
+    """The generator as the GPU runs it against the real Thrust classes' output (tests/golden/thrust_rng.npz,
+    made from the image's rocThrust by tools/make_goldens.py): every uniform bit for bit, u == 1.0 included."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "thrust_rng.npz"))
+    got = api.rng_uniforms(z["seeds"], 4096)
+    assert np.array_equal(got.view(np.uint32), z["uniform"].view(np.uint32))
+    assert (got == 1.0).sum() >= 3
+
+
 def test_primary_hits_pinhole_exact():
     """No lens sampling -> no transcendental on the primary path: ids and t bit-exact."""
     w = h = 256
