@@ -53,6 +53,7 @@ SYMBOLS = {
     "gpt_scene_info": (_I, [_V, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gpt_debug_primary_hits": (_I, [_V, _V, _I, _V, _V]),
     "gpt_debug_intersect": (_I, [_V, _V, _I, _I, _V, _V]),
+    "gpt_debug_render_events": (_I, [_V, _V, _I, _V, _V, _V]),
     "gpt_debug_rng_uniforms": (_I, [_I, _V, _I, _I, _V]),
     "gpt_intersect_noalloc": (_I, [_V, _V, _I, _I, _V, _V]),
     "gpt_kdtree_build": (_I, [_V, _I, _I, c_void_pp]),

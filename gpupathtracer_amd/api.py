@@ -155,6 +155,17 @@ class Scene:
         _check(_lib.lib().gpt_debug_primary_hits(self._h, _ptr(cam), int(counter), _ptr(prim), _ptr(t)))
         return prim, t
 
+    def render_events(self, camera, counter):
+        """gpt_debug_render_events: (pixels[n,3], events[n,depth] uint8, prims[n,depth] int32) of one pass."""
+        cam = _cam(camera)
+        n = self._ensure(cam)
+        depth = max(1, int(self.params["max_depth"][0]))
+        out = np.empty((n, 3), dtype=np.float32)
+        events = np.empty((n, depth), dtype=np.uint8)
+        prims = np.empty((n, depth), dtype=np.int32)
+        _check(_lib.lib().gpt_debug_render_events(self._h, _ptr(cam), int(counter), _ptr(events), _ptr(prims), _ptr(out)))
+        return out, events, prims
+
     def intersect(self, rays, use_kdtree=True):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         tri = np.empty(rays.shape[0], dtype=np.int32)

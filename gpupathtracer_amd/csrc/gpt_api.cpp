@@ -37,7 +37,7 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
 void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
                 int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
-                unsigned long long* stats);
+                unsigned long long* stats, unsigned char* dbg_events, int* dbg_prims, int dbg_stride);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
                  float* pass_out3);
 void gptk_extract_pass(hipStream_t s, int grid, int numPixels, int numPasses, int pass, const float4* pass_rgb, float* out3);
@@ -181,6 +181,9 @@ struct gpt_scene {
     unsigned* d_counters = nullptr;          // GPT_COUNTER_WORDS
     unsigned long long* d_stats = nullptr;   // GPT_STAT_WORDS
     uint64_t passes = 0;
+    // gpt_debug_render_events only: where k_shade records every bounce's branch code and primitive
+    unsigned char* dbg_events = nullptr;
+    int* dbg_prims = nullptr;
 
     // timing
     bool profile = false;
@@ -291,7 +294,7 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
         }
         gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
                    s->d_hit[in], s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_hit[out], s->d_pass, counts,
-                   s->d_stats);
+                   s->d_stats, P == 1 ? s->dbg_events : nullptr, P == 1 ? s->dbg_prims : nullptr, s->params.max_depth);
     }
     gptk_finish(s->stream, pixel_grid(N), N, P, s->d_pass, s->d_image, pass3);
     if (s->kd_stats) gptk_collect_wave_iters(s->stream, s->d_stats);
@@ -747,6 +750,37 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
         memcpy(&prim[pixel], &h[2 * (size_t)i + 1], 4);
     }
     return GPT_OK;
+}
+
+// One pass as gpt_render_pass renders it, plus what every bounce of every path did.
+gpt_status gpt_debug_render_events(gpt_scene* s, const Camera* cam, int counter, unsigned char* events, int32_t* prims,
+                                   float* host_pixels) {
+    gpt_status st = check_render_args(s, cam);
+    if (st) return st;
+    if (!events || !prims) return fail(GPT_ERR_INVALID_ARGUMENT, "null output");
+    GPT_ON_DEVICE(s->device);
+    const size_t n = (size_t)s->numPixels * (size_t)std::max(1, s->params.max_depth);
+    if (hipMalloc((void**)&s->dbg_events, n) != hipSuccess || hipMalloc((void**)&s->dbg_prims, n * 4) != hipSuccess) {
+        st = fail(GPT_ERR_OUT_OF_MEMORY, "event buffers");
+    } else if (hipMemsetAsync(s->dbg_events, 0, n, s->stream) != hipSuccess ||
+               hipMemsetAsync(s->dbg_prims, 0xff, n * 4, s->stream) != hipSuccess) {
+        st = fail(GPT_ERR_HIP, "event buffers: memset");
+    } else {
+        st = enqueue_batch(s, cam, counter, 1, host_pixels ? s->d_pass3 : nullptr);
+        if (st == GPT_OK &&
+            ((host_pixels && hipMemcpyAsync(host_pixels, s->d_pass3, (size_t)s->numPixels * 12, hipMemcpyDeviceToHost, s->stream) != hipSuccess) ||
+             hipMemcpyAsync(events, s->dbg_events, n, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+             hipMemcpyAsync(prims, s->dbg_prims, n * 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+             hipStreamSynchronize(s->stream) != hipSuccess))
+            st = fail(GPT_ERR_HIP, "event download");
+    }
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->dbg_events);
+    (void)hipFree(s->dbg_prims);
+    s->dbg_events = nullptr;
+    s->dbg_prims = nullptr;
+    if (st == GPT_OK) st = collect_events(s);
+    return st;
 }
 
 // The device's uniform streams for the given seeds (parity of the random numbers themselves).

@@ -556,7 +556,9 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 
 // FIRST: the launch that shades the primary rays.  k_camera stores no throughput for them: it is (1, 1, 1),
 // and slot i of the still uncompacted queue belongs to pass i - pixel * numPasses.
-template <bool FIRST>
+// DEBUG: every bounce's branch code (PT_EV_*) and primitive go to dbg_events / dbg_prims at
+// [pixel * dbg_stride + depth] (single-pass launches only; parity checks read them).
+template <bool FIRST, bool DEBUG>
 __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
                                                      int numPasses,
                                                      const float4* __restrict__ in_o,
@@ -569,7 +571,9 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
                                                      float2* __restrict__ out_hit,
                                                      float4* __restrict__ pass_rgb,
                                                      unsigned* __restrict__ counts,
-                                                     unsigned long long* __restrict__ stats) {
+                                                     unsigned long long* __restrict__ stats,
+                                                     unsigned char* __restrict__ dbg_events,
+                                                     int* __restrict__ dbg_prims, int dbg_stride) {
     __shared__ float4 s_o[SHADE_STAGE];
     __shared__ float4 s_d[SHADE_STAGE];
     __shared__ float4 s_t[SHADE_STAGE];
@@ -646,8 +650,13 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
             }
             V3 add;
             bool has_add;
+            int event = 0;
             alive = shade_bounce(o, d, thr, medium, sa, ss, prim != PT_PRIM_MISS, bestT, nrm, m, matIndex,
-                                 pixel, depth, seed0 + pass, sp, add, has_add);
+                                 pixel, depth, seed0 + pass, sp, add, has_add, event);
+            if (DEBUG) {
+                dbg_events[(size_t)pixel * (size_t)dbg_stride + (size_t)depth] = (unsigned char)event;
+                dbg_prims[(size_t)pixel * (size_t)dbg_stride + (size_t)depth] = prim;
+            }
             if (has_add) {
                 const size_t slot = (size_t)pixel * (size_t)numPasses + (size_t)pass;
                 float4 acc = pass_rgb[slot];
@@ -851,13 +860,14 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
 void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
                 int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
-                unsigned long long* stats) {
-    if (depth == 0)
-        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
-                       out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats);
-    else
-        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, in_thr, hit,
-                       out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats);
+                unsigned long long* stats, unsigned char* dbg_events, int* dbg_prims, int dbg_stride) {
+#define GPT_LAUNCH_SHADE(FIRST, DEBUG)                                                                                       \
+    hipLaunchKernelGGL((k_shade<FIRST, DEBUG>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, \
+                       in_thr, hit, out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats, dbg_events, dbg_prims, dbg_stride)
+    const bool debug = dbg_events != nullptr && dbg_prims != nullptr;
+    if (depth == 0) { if (debug) GPT_LAUNCH_SHADE(true, true); else GPT_LAUNCH_SHADE(true, false); }
+    else { if (debug) GPT_LAUNCH_SHADE(false, true); else GPT_LAUNCH_SHADE(false, false); }
+#undef GPT_LAUNCH_SHADE
 }
 
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,

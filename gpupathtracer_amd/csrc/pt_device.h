@@ -326,12 +326,20 @@ PT_HD V3 transmission_color(V3 absorption, float distance) {
 // `hit` says whether anything was hit; `n`, `m`, `hit_mat_index` describe it.
 // `add` receives what the reference adds to accumulatedColors this bounce
 // (returned through has_add so exact zeros are not even added).
+// `event` receives the branch the bounce left through (PT_EV_*, | PT_EV_KILLED when the weight
+// test ended the path): what parity checks compare before they compare radiance.
 // Returns true while the path stays alive.
+#define PT_EV_SCATTER  1   // scattered inside the medium (:567-590)
+#define PT_EV_REFLECT  2   // specular reflection (:665-676)
+#define PT_EV_TRANSMIT 3   // refraction into / out of the material (:678-683)
+#define PT_EV_DIFFUSE  4   // diffuse bounce (:685-703)
+#define PT_EV_MISS     5   // nothing hit: sky (:709-716)
+#define PT_EV_KILLED   8   // length(throughput) <= MIN_RAY_WEIGHT (:583, :705)
 PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
                         V3 cur_sigma_a, float cur_sigma_s,
                         bool hit, float bestT, V3 n, const Mat& m, int hit_mat_index,
                         int pixelIndex, int rayDepth, uint32_t seedOrPass,
-                        const ShadeParams& P, V3& add, bool& has_add) {
+                        const ShadeParams& P, V3& add, bool& has_add, int& event) {
     has_add = false;
     Rng rng;
     rng.seed(randhash(seedOrPass) * randhash((uint32_t)pixelIndex) * randhash((uint32_t)rayDepth));
@@ -347,7 +355,9 @@ PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
             d = direction_in_sphere(xi1, xi2);
             o = no;
             thr = thr * transmission_color(cur_sigma_a, scatteringDistance);
-            return !((double)length(thr) <= P.min_ray_weight);
+            const bool aliveS = !((double)length(thr) <= P.min_ray_weight);
+            event = aliveS ? PT_EV_SCATTER : (PT_EV_SCATTER | PT_EV_KILLED);
+            return aliveS;
         }
         thr = thr * transmission_color(cur_sigma_a, bestT);
     }
@@ -355,6 +365,7 @@ PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
     if (!hit) {
         add = thr * background_color(d);       // (:712)
         has_add = true;
+        event = PT_EV_MISS;
         return false;
     }
 
@@ -380,14 +391,17 @@ PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
         roulette < fresnel_reflection(n, incident, iorIncident, iorTransmitted, transmissionDirection);
 
     if (reflectFromSurface) {
+        event = PT_EV_REFLECT;
         thr = thr * m.specular;
         o = point + biasVector;
         d = reflectionDirection;
     } else if (m.transmits) {
+        event = PT_EV_TRANSMIT;
         medium = mediumTransmitted;
         o = point - biasVector;
         d = transmissionDirection;
     } else {
+        event = PT_EV_DIFFUSE;
         // accumulated += notAbsorbed * emitted (:690).  A zero emitted colour with a
         // finite throughput adds exact zeros, which is skipped.
         bool zeroEmission = (m.emitted.x == 0.0f && m.emitted.y == 0.0f && m.emitted.z == 0.0f);
@@ -400,7 +414,9 @@ PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
         o = point + biasVector;
         d = cosine_weighted_direction(n, r1, r2);
     }
-    return !((double)length(thr) <= P.min_ray_weight);
+    const bool alive = !((double)length(thr) <= P.min_ray_weight);
+    if (!alive) event |= PT_EV_KILLED;
+    return alive;
 }
 
 }  // namespace pt

@@ -272,6 +272,16 @@ gpt_status gpt_debug_primary_hits(gpt_scene* scene, const Camera* camera, int co
 gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int use_kdtree,
                                int32_t* tri, float* t);
 
+/* gpt_render_pass plus a record of what every bounce of every path did (debug/parity).
+ * events[pixel * max_depth + depth]: 0 = the path was not alive at that depth, else the branch
+ * traceRayKernel left through -- 1 scattered in a medium (:567-590), 2 specular reflection
+ * (:665-676), 3 transmission (:678-683), 4 diffuse bounce (:685-703), 5 miss / sky (:709-716) --
+ * plus 8 when the weight test (:583, :705) ended the path there.  prims[...]: the primitive hit at
+ * that bounce (encoding of gpt_debug_primary_hits; -1 also where not alive).  Host arrays of
+ * numPixels x max_depth entries; host_pixels as in gpt_render_pass. */
+gpt_status gpt_debug_render_events(gpt_scene* scene, const Camera* camera, int counter,
+                                   unsigned char* events, int32_t* prims, float* host_pixels);
+
 /* The device's random numbers (debug/parity): out[s * n_draws + k] = k-th uniform of an engine
  * seeded with seeds[s] -- thrust::default_random_engine + uniform_real_distribution<float>(0,1)
  * as used at path_tracer_kernel.cu:139-142, 492-493.  Host arrays. */

@@ -320,6 +320,16 @@ typedef struct orc_hit {
     float   t;
 } orc_hit;
 
+/* What one traceRayKernel invocation did with its path (for parity of the branches taken):
+ * the branch of :567 / :665 / :678 / :685 / :709 it left through, plus ORC_EV_KILLED when the
+ * weight test (:583, :705) ended the path.  0 = the path was not alive at that depth. */
+#define ORC_EV_SCATTER  1
+#define ORC_EV_REFLECT  2
+#define ORC_EV_TRANSMIT 3
+#define ORC_EV_DIFFUSE  4
+#define ORC_EV_MISS     5
+#define ORC_EV_KILLED   8
+
 /* ---- traceRayKernel, one active path (:477-725) --------------------------
  * State of the path is passed by pointer (the reference indexes its per-pixel
  * arrays by pixelIndex).  Returns 1 while the path stays alive, 0 when the
@@ -327,8 +337,10 @@ typedef struct orc_hit {
 static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
                       int pixelIndex, int rayDepth, uint32_t seedOrPass, const orc_params* P,
                       Ray* ray, AbsorptionAndScatteringProperties* medium,
-                      f3* notAbsorbed, f3* accumulated, orc_hit* hit_out) {
+                      f3* notAbsorbed, f3* accumulated, orc_hit* hit_out, int* event_out) {
     Ray currentRay = *ray;
+    int event_dummy;
+    if (!event_out) event_out = &event_dummy;
     orc_rng rng;
     rng_seed(&rng, orc_randhash(seedOrPass) * orc_randhash((uint32_t)pixelIndex) *
                        orc_randhash((uint32_t)rayDepth));
@@ -389,7 +401,8 @@ static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sph
                 *ray = nextRay;
                 *notAbsorbed = mul3(*notAbsorbed,
                                     transmission_color(cur.absorptionCoefficient, scatteringDistance));
-                if (length3(*notAbsorbed) <= P->min_ray_weight) return 0;
+                *event_out = ORC_EV_SCATTER;
+                if (length3(*notAbsorbed) <= P->min_ray_weight) { *event_out |= ORC_EV_KILLED; return 0; }
                 return 1;
             } else {
                 *notAbsorbed = mul3(*notAbsorbed, transmission_color(cur.absorptionCoefficient, bestT));
@@ -436,6 +449,7 @@ static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sph
                                                                     transmittedMedium.refractiveIndex,
                                                                     transmissionDirection));
         (void)reflectionDirection;
+        *event_out = reflectFromSurface ? ORC_EV_REFLECT : bestMaterial.hasTransmission ? ORC_EV_TRANSMIT : ORC_EV_DIFFUSE;
         if (reflectFromSurface) {
             *notAbsorbed = mul3(*notAbsorbed, bestMaterial.specularColor);
             ray->origin = add3(bestIntersectionPoint, biasVector);
@@ -452,10 +466,11 @@ static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sph
             ray->origin = add3(bestIntersectionPoint, biasVector);
             ray->direction = cosine_weighted_direction(bestNormal, randomFloat1, randomFloat2);
         }
-        if (length3(*notAbsorbed) <= P->min_ray_weight) return 0;
+        if (length3(*notAbsorbed) <= P->min_ray_weight) { *event_out |= ORC_EV_KILLED; return 0; }
         return 1;
     } else {
         *accumulated = add3(*accumulated, mul3(*notAbsorbed, background_color(currentRay.direction)));
+        *event_out = ORC_EV_MISS;
         return 0;
     }
 }
@@ -469,12 +484,17 @@ static int trace_path(int numPolys, const Poly* polys, int numSpheres, const Sph
  * live_at_depth (may be NULL): max_depth entries, number of live paths that
  *            enter each depth (numActivePixels at each traceRayKernel launch).
  * first_hit (may be NULL): n entries, closest hit of the primary rays.
- * Returns sum over depths of live paths (path-bounces of this pass). */
-int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
-                        int numPixels, const int32_t* pixel_ids, int n,
-                        int counter, const Camera* camera, const orc_params* P,
-                        float* out_rgb, int64_t* live_at_depth, orc_hit* first_hit) {
+ * events / prims (may be NULL): n x max_depth entries, [k * max_depth + depth]: the ORC_EV_* code and
+ *            the primitive hit (orc_hit.prim encoding) of every bounce of every listed path; 0 / -1
+ *            where the path was no longer alive. */
+int64_t orc_render_pass_ex(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
+                           int numPixels, const int32_t* pixel_ids, int n,
+                           int counter, const Camera* camera, const orc_params* P,
+                           float* out_rgb, int64_t* live_at_depth, orc_hit* first_hit,
+                           uint8_t* events, int32_t* prims) {
     if (!pixel_ids) n = numPixels;
+    if (events) memset(events, 0, (size_t)n * (size_t)P->max_depth);
+    if (prims) for (size_t i = 0; i < (size_t)n * (size_t)P->max_depth; i++) prims[i] = -1;
     int* activePixels = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
     Ray* rays = (Ray*)malloc(sizeof(Ray) * (size_t)(n > 0 ? n : 1));
     AbsorptionAndScatteringProperties* mediums =
@@ -503,9 +523,13 @@ int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const S
         for (int a = 0; a < numActive; a++) {
             int k = activePixels[a];
             int pix = pixel_ids ? pixel_ids[k] : k;
-            orc_hit* h = (first_hit && rayDepth == 0) ? &first_hit[k] : NULL;
+            orc_hit hrec;
+            int ev = 0;
             int alive = trace_path(numPolys, polys, numSpheres, spheres, pix, rayDepth, seed, P,
-                                   &rays[k], &mediums[k], &notAbsorbed[k], &accumulated[k], h);
+                                   &rays[k], &mediums[k], &notAbsorbed[k], &accumulated[k], &hrec, &ev);
+            if (first_hit && rayDepth == 0) first_hit[k] = hrec;
+            if (events) events[(size_t)k * (size_t)P->max_depth + (size_t)rayDepth] = (uint8_t)ev;
+            if (prims) prims[(size_t)k * (size_t)P->max_depth + (size_t)rayDepth] = hrec.prim;
             if (!alive) activePixels[a] = -1;
         }
         /* thrust::remove_if(..., isNegative()) (:811-813, :731-738): stable */
@@ -521,6 +545,15 @@ int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const S
     }
     free(activePixels); free(rays); free(mediums); free(notAbsorbed); free(accumulated);
     return total;
+}
+
+/* Returns sum over depths of live paths (path-bounces of this pass). */
+int64_t orc_render_pass(int numPolys, const Poly* polys, int numSpheres, const Sphere* spheres,
+                        int numPixels, const int32_t* pixel_ids, int n,
+                        int counter, const Camera* camera, const orc_params* P,
+                        float* out_rgb, int64_t* live_at_depth, orc_hit* first_hit) {
+    return orc_render_pass_ex(numPolys, polys, numSpheres, spheres, numPixels, pixel_ids, n, counter, camera, P,
+                              out_rgb, live_at_depth, first_hit, NULL, NULL);
 }
 
 /* Primary rays only (raycastFromCameraKernel), n x 6 floats origin,direction. */

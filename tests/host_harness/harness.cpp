@@ -183,8 +183,9 @@ int64_t hh_render_pass(void* tree_or_null, int numPolys, const Poly* polys, int 
                 Mat q = to_mat(mm); sa = q.sigma_a; ss = q.sigma_s;
             }
             V3 add; bool has_add;
+            int event = 0;
             bool alive = shade_bounce(o, d, thr, medium, sa, ss, prim != PT_PRIM_MISS, bestT, nrm, m, matIndex,
-                                      pix, depth, seed, sp, add, has_add);
+                                      pix, depth, seed, sp, add, has_add, event);
             if (has_add) acc = acc + add;
             if (!alive) break;
         }

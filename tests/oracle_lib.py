@@ -53,6 +53,8 @@ def lib():
             ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
             ctypes.c_void_p, ctypes.POINTER(OrcParams),
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_render_pass_ex.restype = ctypes.c_int64
+        L.orc_render_pass_ex.argtypes = L.orc_render_pass.argtypes + [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_camera_rays.argtypes = [
             ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
             ctypes.c_void_p, ctypes.POINTER(OrcParams), ctypes.c_void_p]
@@ -93,8 +95,9 @@ def uniform_stream(seed, n):
     return out
 
 
-def render_pass(spheres, polys, camera, counter, p, pixel_ids=None, want_hits=False):
-    """One pass of the reference algorithm.  Returns dict(rgb, live, bounces[, hits])."""
+def render_pass(spheres, polys, camera, counter, p, pixel_ids=None, want_hits=False, want_events=False):
+    """One pass of the reference algorithm.  Returns dict(rgb, live, bounces[, hits][, events, prims]);
+    events / prims: [n, max_depth], the branch code (ORC_EV_*) and primitive of every bounce."""
     spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
     polys = np.ascontiguousarray(polys, dtype=POLY_DTYPE) if polys is not None else np.zeros(0, POLY_DTYPE)
     cam = np.array(camera, dtype=CAMERA_DTYPE).reshape(1)
@@ -107,10 +110,14 @@ def render_pass(spheres, polys, camera, counter, p, pixel_ids=None, want_hits=Fa
     rgb = np.empty((n, 3), dtype=np.float32)
     live = np.zeros(p.max_depth, dtype=np.int64)
     hits = np.empty(n, dtype=HIT_DTYPE) if want_hits else None
-    total = lib().orc_render_pass(
+    events = np.empty((n, p.max_depth), dtype=np.uint8) if want_events else None
+    prims = np.empty((n, p.max_depth), dtype=np.int32) if want_events else None
+    total = lib().orc_render_pass_ex(
         polys.size, _ptr(polys), spheres.size, _ptr(spheres), num_pixels, _ptr(pixel_ids), n,
-        int(counter), _ptr(cam), ctypes.byref(p), _ptr(rgb), _ptr(live), _ptr(hits))
+        int(counter), _ptr(cam), ctypes.byref(p), _ptr(rgb), _ptr(live), _ptr(hits), _ptr(events), _ptr(prims))
     out = {"rgb": rgb, "live": live, "bounces": int(total)}
+    if want_events:
+        out["events"], out["prims"] = events, prims
     if want_hits:
         out["hits"] = hits
     return out
