@@ -22,10 +22,19 @@ def same_paths(ev_got, prim_got, ev_ref, prim_ref):
     return (ev_got == ev_ref).all(axis=1) & (prim_got == prim_ref).all(axis=1)
 
 
-def check_pass(got, ev_got, prim_got, ref, max_flip_fraction, ids=None):
+def flip_bound(n):
+    """Allowed fraction of samples whose path differs.  Measured on MI355X over every scene of the tests
+    (tools/measure_flips.py, ~600 000 samples): none.  The bound is 5e-5 of the samples, and never
+    fewer than two samples."""
+    return max(2, int(np.ceil(5e-5 * n))) / float(max(1, n))
+
+
+def check_pass(got, ev_got, prim_got, ref, max_flip_fraction=None, ids=None):
     """`ref`: oracle render_pass(..., want_events=True) result; `ids`: the pixel subset it covers."""
     if ids is not None:
         got, ev_got, prim_got = got[ids], ev_got[ids], prim_got[ids]
+    if max_flip_fraction is None:
+        max_flip_fraction = flip_bound(got.shape[0])
     same = same_paths(ev_got, prim_got, ref["events"], ref["prims"])
     r = rel_err(got, ref["rgb"])
     worst_same = float(r[same].max()) if same.any() else 0.0

@@ -141,3 +141,17 @@ def geometric_normals(verts):
     ln = np.sqrt((n * n).sum(axis=1, dtype=f32)).astype(f32)
     ln[ln == 0] = 1
     return (n / ln[:, None]).astype(f32)
+
+
+def cornell_box(box_verts, box_normals):
+    """A Cornell-style room from the reference's box.obj (a cube of +-0.8): scaled x3 and lifted so that its
+    floor lies in the ground plane y = -0.8; the front (+z) wall is left out so that the default orbit
+    camera, which stands outside at z = 3.8, looks in, and so is the floor (the kernel's hard-coded ground
+    plane is the floor).  Left wall `red`, right wall `green`, back wall `white`, ceiling `light`
+    (the only emitter).  box.obj's faces come in pairs: front, top, back, bottom, right, left."""
+    v = np.asarray(box_verts, dtype=f32).reshape(-1, 3, 3)
+    v = (v * f32(3.0) + np.array([0.0, 1.6, 0.0], dtype=f32)).astype(f32).reshape(-1, 9)
+    n = np.asarray(box_normals, dtype=f32).reshape(-1, 3)
+    walls = [(2, "light"), (3, "light"), (4, "white"), (5, "white"), (8, "green"), (9, "green"), (10, "red"), (11, "red")]
+    polys = np.concatenate([polys_from_triangles(v[i:i + 1], n[i:i + 1], MATERIALS[m]) for i, m in walls])
+    return polys

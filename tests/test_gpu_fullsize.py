@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import parity
 import scenes as S
 from gpupathtracer_amd import api, meshes
 
@@ -23,6 +24,15 @@ def strided_ids(w, h, stride):
     return (ys * w + xs).astype(np.int32).ravel()
 
 
+def check_subset(sc, sph, polys, cam, counter, depth, ids):
+    """One full-frame pass on the GPU; paths and radiance of the pixels `ids` against the oracle."""
+    got, ev, pr = sc.render_events(cam, counter)
+    ref = O.render_pass(sph, polys, cam, counter, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids,
+                        want_events=True, want_hits=True)
+    parity.check_pass(got, ev, pr, ref, ids=ids)
+    return got, pr, ref
+
+
 def test_spheres_1080p_against_oracle_subset():
     """Config: the reference's default scene at 1920x1080 (width-stride fix), depth 8."""
     w, h, depth = 1920, 1080, 8
@@ -30,47 +40,53 @@ def test_spheres_1080p_against_oracle_subset():
     sph = S.default_spheres()
     ids = strided_ids(w, h, 13)
     with api.Scene(sph, None, api.render_params(max_depth=depth)) as sc:
-        got = sc.render_pass(cam, 4)
+        got, _, _ = check_subset(sc, sph, None, cam, 4, depth, ids)
         again = sc.render_pass(cam, 4)
         st = sc.stats()
     assert np.array_equal(got, again)                       # deterministic
-    ref = O.render_pass(sph, None, cam, 4, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids)
-    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
-    assert (rel > 1e-4).mean() < 2e-3
     assert st["live_at_depth"][0] == 2 * w * h
     # bounces per path of the default scene at depth 8 (reference run: 2.69 at 512x512)
     assert 2.4 < st["path_bounces"] / (2 * w * h) < 3.0
 
 
 def test_cow_heavy_1080p_kd_vs_brute_and_oracle():
-    """Config: cow subdivided 3x (371 456 triangles, glass) + default spheres, 1080p, depth 8."""
+    """Config (the benchmark's workload): cow subdivided 4x (1 485 824 triangles, glass) + default spheres,
+    1080p, depth 8, on the tree the benchmark runs on."""
     w, h, depth = 1920, 1080, 8
     cam = S.orbit_camera(w, h)
     sph = S.default_spheres()
     v, n = meshes.load_asset("cow")
-    v, n = meshes.subdivide(v, n, 3)
+    v, n = meshes.subdivide(v, n, 4)
+    assert v.shape[0] == 1485824
     polys = meshes.polys_from_triangles(v, n, S.MATERIALS["glass"])
     with api.Scene(sph, polys, api.render_params(max_depth=depth)) as sc:
-        prim, t = sc.primary_hits(cam, 0)
-        # primary rays of a strided subset: traversal vs the brute-force loop on the device, bit-exact
+        # traversal vs the brute-force loop on the device, bit-exact: primary rays of a strided pixel subset,
+        # and rays between random points around the mesh (what bounces inside the glass look like)
         ids = strided_ids(w, h, 9)
         rays = O.camera_rays(cam, 0, O.params(row_stride_is_width=1), pixel_ids=ids)
+        rng = np.random.default_rng(3)
+        pts = v.reshape(-1, 3)
+        lo, hi = pts.min(axis=0), pts.max(axis=0)
+        m = 12000
+        o = (lo + (hi - lo) * rng.random((m, 3), dtype=np.float32)).astype(np.float32)
+        d = pts[rng.integers(0, pts.shape[0], m)] - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        rays = np.concatenate([rays, np.concatenate([o, d], axis=1)]).astype(np.float32)
         tk, ttk = sc.intersect(rays, use_kdtree=True)
         tb, ttb = sc.intersect(rays, use_kdtree=False)
         assert np.array_equal(tk, tb) and np.array_equal(ttk.view(np.int32), ttb.view(np.int32))
-        assert (tb >= 0).sum() > 500
-        got = sc.render_pass(cam, 0)
+        assert (tb[:ids.size] >= 0).sum() > 500 and (tb[ids.size:] >= 0).sum() > m // 2
+        # and the device's brute force is the oracle's loop
+        to, tto = O.closest_triangle(v, rays[-300:])
+        assert np.array_equal(to, tb[-300:]) and np.array_equal(tto.view(np.int32), ttb[-300:].view(np.int32))
+        # paths, first-hit triangle indices and radiance of ~3 000 pixels against the oracle (brute force)
+        ids = strided_ids(w, h, 26)
+        got, pr, ref = check_subset(sc, sph, polys, cam, 0, depth, ids)
         info = sc.info()
     assert info["kd_depth"] <= 56 and info["kd_nodes"] > 1000
-    # first-hit triangle indices of primary rays against the oracle (brute force, pixel subset)
-    ids = strided_ids(w, h, 40)
-    ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids,
-                        want_hits=True)
-    assert (prim[ids] != ref["hits"]["prim"]).mean() < 2e-3          # lens sincos last-bit cases only
     on_mesh = (ref["hits"]["prim"] >= 0) & (ref["hits"]["prim"] < polys.size)
-    assert on_mesh.sum() > 20
-    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
-    assert (rel > 1e-4).mean() < 1e-2
+    assert on_mesh.sum() > 50
+    assert np.array_equal(pr[ids][:, 0], ref["hits"]["prim"])
 
 
 def test_passes_per_launch_do_not_change_the_image():
@@ -93,16 +109,21 @@ def test_passes_per_launch_do_not_change_the_image():
         assert np.array_equal(img, images[0][0]) and pb == images[0][1] and np.array_equal(live, images[0][2])
 
 
-def test_converged_image_rmse_against_oracle():
-    """Image-level agreement: 64 spp of the box scene, RMSE of the mean image."""
-    w = h = 128
+def test_box_scene_512_64spp_rmse_against_oracle():
+    """Config: Cornell-style room built from the reference's box.obj (tests/scenes.py: cornell_box) around the
+    default spheres, 512x512, 64 spp, depth 8.  The image after 64 passes against the oracle's: both add the
+    passes in counter order in float32, so the images differ only by the per-sample rounding differences."""
+    w = h = 512
     spp, depth = 64, 8
     cam = S.orbit_camera(w, h)
     sph = S.default_spheres()
     bv, bn = meshes.load_asset("box")
-    bv = meshes.transform(bv, 0.35, (0.0, -0.45, 1.9))
-    polys = meshes.polys_from_triangles(bv, bn, S.MATERIALS["glass"])
+    polys = S.cornell_box(bv, bn)
     with api.Scene(sph, polys, api.render_params(max_depth=depth)) as sc:
+        got0, ev, pr = sc.render_events(cam, 0)
+        ref0 = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), want_events=True)
+        parity.check_pass(got0, ev, pr, ref0)
+        assert ((pr >= 0) & (pr < polys.size)).mean() > 0.2          # the walls are in view
         sc.reset(w * h)
         sc.render_range(cam, 0, spp)
         img, passes = sc.accum_download()
@@ -113,11 +134,11 @@ def test_converged_image_rmse_against_oracle():
         ref += O.render_pass(sph, polys, cam, c, p)["rgb"]
     a, b = img / spp, ref / spp
     rmse = float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
-    # a branch flip changes one sample of one pixel by O(1); at 64 spp and <0.2 % flipped samples the
-    # mean image moves by far less than the Monte-Carlo noise (~0.05).  Bound: 2e-3.
-    assert rmse < 2e-3, rmse
-    assert np.array_equal(api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp), np.zeros((w * h, 3), bool)) or \
-        (api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp)).mean() < 5e-3
+    # Monte-Carlo noise of this image at 64 spp is ~0.05; the bound is the stated tolerance of the
+    # converged-image comparison: 2e-4 absolute RMSE (about one flipped sample in 10^5 would reach it)
+    assert rmse < 2e-4, rmse
+    assert np.abs(a - b).max() < 0.05                      # no single pixel off by a whole sample
+    assert (api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp)).mean() < 1e-3
 
 
 def test_headless_renderer_cli(tmp_path):
@@ -140,31 +161,27 @@ def test_headless_renderer_cli(tmp_path):
     assert raw[len(header):] == api.tonemap_8bit(img, 6).tobytes()
 
 
-def test_synthetic_soup_4k():
-    """Config: synthetic triangle soup (2 M here; the bench workload uses 10 M) at 3840x2160."""
+def test_synthetic_soup_10m_4k():
+    """Config: synthetic soup of 10 M triangles at 3840x2160 (the benchmark's `soup` workload)."""
     w, h, depth = 3840, 2160, 8
     cam = S.orbit_camera(w, h)
     sph = S.default_spheres()
-    v, n = meshes.random_soup(2000000, seed=12345, extent=1.0, edge=0.01)
+    v, n = meshes.random_soup(10000000, seed=12345, extent=1.0, edge=0.01)
     v = meshes.transform(v, 0.75, (0.0, 0.1, 0.0))
     polys = meshes.polys_from_triangles(v, n, S.MATERIALS["white"])
     with api.Scene(sph, polys, api.render_params(max_depth=depth, passes_in_flight=2)) as sc:
         ids = strided_ids(w, h, 24)
         rays = O.camera_rays(cam, 1, O.params(row_stride_is_width=1), pixel_ids=ids)
         tk, ttk = sc.intersect(rays, use_kdtree=True)
-        to, tto = O.closest_triangle(v, rays[:1500])
-        assert np.array_equal(tk[:1500], to) and np.array_equal(ttk[:1500].view(np.int32), tto.view(np.int32))
+        to, tto = O.closest_triangle(v, rays[:600])
+        assert np.array_equal(tk[:600], to) and np.array_equal(ttk[:600].view(np.int32), tto.view(np.int32))
         assert (tk >= 0).sum() > 1000
         sc.reset(w * h)
         sc.render_range(cam, 0, 2)
         img, passes = sc.accum_download()
         st = sc.stats()
-    assert passes == 2 and st["live_at_depth"][0] == 2 * w * h
-    assert np.isfinite(img).all() and img.min() >= 0 and 0.05 < img.mean() / 2 < 1.0
-    # one pass of a pixel subset against the oracle
-    ids = strided_ids(w, h, 90)
-    with api.Scene(sph, polys, api.render_params(max_depth=depth, passes_in_flight=1)) as sc:
-        got = sc.render_pass(cam, 0)
-    ref = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), pixel_ids=ids)
-    rel = (np.abs(got[ids] - ref["rgb"]) / np.maximum(np.abs(ref["rgb"]), 1e-3)).max(axis=1)
-    assert (rel > 1e-4).mean() < 1e-2
+        assert passes == 2 and st["live_at_depth"][0] == 2 * w * h
+        assert np.isfinite(img).all() and img.min() >= 0 and 0.05 < img.mean() / 2 < 1.0
+        # paths and radiance of ~1 000 pixels of one pass against the oracle (brute force over 10 M triangles)
+        ids = strided_ids(w, h, 90)
+        check_subset(sc, sph, polys, cam, 0, depth, ids)
