@@ -123,7 +123,7 @@ def test_box_scene_512_64spp_rmse_against_oracle():
         got0, ev, pr = sc.render_events(cam, 0)
         ref0 = O.render_pass(sph, polys, cam, 0, O.params(max_depth=depth, row_stride_is_width=1), want_events=True)
         parity.check_pass(got0, ev, pr, ref0)
-        assert ((pr >= 0) & (pr < polys.size)).mean() > 0.2          # the walls are in view
+        assert ((pr[:, 0] >= 0) & (pr[:, 0] < polys.size)).mean() > 0.2    # the walls are in view of the primary rays
         sc.reset(w * h)
         sc.render_range(cam, 0, spp)
         img, passes = sc.accum_download()
@@ -137,7 +137,9 @@ def test_box_scene_512_64spp_rmse_against_oracle():
     # Monte-Carlo noise of this image at 64 spp is ~0.05; the bound is the stated tolerance of the
     # converged-image comparison: 2e-4 absolute RMSE (about one flipped sample in 10^5 would reach it)
     assert rmse < 2e-4, rmse
-    assert np.abs(a - b).max() < 0.05                      # no single pixel off by a whole sample
+    # pixels that differ visibly hold a sample whose path took another branch: as rare as those are
+    off = int((np.abs(a - b).max(axis=1) > 1e-3).sum())
+    assert off <= parity.flip_bound(w * h * spp) * w * h * spp, off
     assert (api.tonemap_8bit(img, spp) != O.tonemap_8bit(ref, spp)).mean() < 1e-3
 
 
