@@ -63,6 +63,7 @@ SYMBOLS = {
     "gpt_kdtree_free": (None, [_V]),
     "launchKernel": (None, None),   # Camera is passed by value: bound in api.launch_kernel
     "gpt_launch_kernel_params": (None, [_V]),
+    "gpt_launch_kernel_static_scene": (None, [_I]),
     "gpt_device_alloc": (_I, [c_void_pp, ctypes.c_size_t]),
     "gpt_device_upload": (_I, [_V, _V, ctypes.c_size_t]),
     "gpt_device_download": (_I, [_V, _V, ctypes.c_size_t]),

@@ -180,6 +180,7 @@ struct gpt_scene {
     float* d_pass3 = nullptr;
     unsigned* d_counters = nullptr;          // GPT_COUNTER_WORDS
     unsigned long long* d_stats = nullptr;   // GPT_STAT_WORDS
+    unsigned long long* d_stats_scratch = nullptr;   // same size: for queries that must not touch the statistics
     uint64_t passes = 0;
     // gpt_debug_render_events only: where k_shade records every bounce's branch code and primitive
     unsigned char* dbg_events = nullptr;
@@ -257,7 +258,7 @@ int pixel_grid(int numPixels) {
 
 // Enqueue `P` consecutive passes (counters counter0 .. counter0+P-1) traced together:
 // every kernel launch covers the live paths of all P passes.  pass3: optional device
-// buffer receiving the (last) pass as packed float3.
+// buffer of P x numPixels x 3 floats receiving every pass on its own as packed float3.
 gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, float* pass3) {
     const int N = s->numPixels;
     const uint32_t seed0 = (uint32_t)counter0;
@@ -276,6 +277,8 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
     gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, seed0,
                 s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+    // (the first shade launch initialises the pass radiance slots; without any bounce nobody does)
+    if (s->params.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_pass, 0, (size_t)total * sizeof(float4), s->stream));
     // every ray arrives with its closest ground / sphere hit: without triangles there is nothing to intersect
     const bool trace = s->geom.n_tris > 0 || s->kd_stats;
     const int grid = (int)std::max<long long>(1, std::min<long long>(kTraceGrid, (total + kBlock - 1) / kBlock));
@@ -377,7 +380,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
             sph[4 * (size_t)i + 0] = spheres[i].position.x;
             sph[4 * (size_t)i + 1] = spheres[i].position.y;
             sph[4 * (size_t)i + 2] = spheres[i].position.z;
-            sph[4 * (size_t)i + 3] = spheres[i].radius;
+            sph[4 * (size_t)i + 3] = spheres[i].radius * spheres[i].radius;   // the test needs radius^2 only (:255)
             sph_mat[(size_t)i] = mt.add(spheres[i].material);
         }
         std::vector<TriRec> recs((size_t)numPolys);
@@ -501,7 +504,8 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         if (spill_words >> 32) { st = fail(GPT_ERR_TOO_LARGE, "kd-tree too deep for the traversal stack"); break; }
         if (hipMalloc((void**)&s->d_spill, spill_words * 4) != hipSuccess) { st = fail(GPT_ERR_OUT_OF_MEMORY, "spill buffer"); break; }
         if (hipMalloc((void**)&s->d_counters, sizeof(unsigned) * GPT_COUNTER_WORDS) != hipSuccess ||
-            hipMalloc((void**)&s->d_stats, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) {
+            hipMalloc((void**)&s->d_stats, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess ||
+            hipMalloc((void**)&s->d_stats_scratch, sizeof(unsigned long long) * GPT_STAT_WORDS) != hipSuccess) {
             st = fail(GPT_ERR_OUT_OF_MEMORY, "counters");
             break;
         }
@@ -544,7 +548,7 @@ gpt_status gpt_scene_destroy(gpt_scene* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     free_pixel_buffers(s);
     void* ptrs[] = {s->d_spheres, s->d_sphere_mat, s->d_tris, s->d_leaf_tris, s->d_refs, s->d_tri_nm, s->d_mats, s->d_nodes,
-                    s->d_spill, s->d_counters, s->d_stats};
+                    s->d_spill, s->d_counters, s->d_stats, s->d_stats_scratch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -728,9 +732,8 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     gptk_camera(s->stream, pixel_grid(N), &s->geom, &cp, N, 1, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0],
                 s->d_thr[0], s->d_hit[0], s->d_pass, counts);
     const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
-    // statistics are not touched by this query: use a scratch copy of the stats words
-    unsigned long long* scratch_stats = nullptr;
-    HIP_TRY(hipMalloc((void**)&scratch_stats, sizeof(unsigned long long) * GPT_STAT_WORDS));
+    // statistics are not touched by this query: the kernel gets the scene's scratch copy of the stats words
+    unsigned long long* scratch_stats = s->d_stats_scratch;
     HIP_TRY(hipMemsetAsync(scratch_stats, 0, sizeof(unsigned long long) * GPT_STAT_WORDS, s->stream));
     const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
     gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, 0, s->d_ray_o[0], s->d_ray_d[0], s->d_hit[0], counts, work,
@@ -740,7 +743,6 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     HIP_TRY(hipMemcpyAsync(h.data(), s->d_hit[0], h.size() * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(ro.data(), s->d_ray_o[0], ro.size() * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipFree(scratch_stats));
     // queue slots are not in pixel order: each slot carries its pixel index
     for (int i = 0; i < N; i++) {
         int pixel;
@@ -1111,6 +1113,13 @@ gpt_status gpt_device_free(void* ptr) {
 
 // ---- launchKernel ---------------------------------------------------------------
 namespace {
+// Passes traced ahead of the caller, pass after pass as packed float3 (what a call hands over).
+struct LookAhead {
+    float* d_img3 = nullptr;      // count x numPixels x 3 floats
+    Camera cam;
+    int begin = 0, count = 0;     // counters [begin, begin + count); count == 0: empty
+    hipEvent_t done = nullptr;    // recorded behind the batch on the scene's stream
+};
 struct LaunchCache {
     std::mutex mu;
     gpt_scene* scene = nullptr;
@@ -1119,11 +1128,15 @@ struct LaunchCache {
     unsigned long long checksum = 0;
     gpt_render_params params;
     bool params_set = false;
+    bool assume_static = false;
+    int device = -1;
+    hipStream_t copy = nullptr;               // checksum + device-to-host copies, beside the scene's tracing stream
     unsigned long long* d_sum = nullptr;
-    // look-ahead: the passes rendered beyond the one asked for, kept on the device
-    Camera cam;                 // camera of the batch in s->d_pass
-    int ahead_begin = 0, ahead_count = 0;
-    int last_counter = 0, streak = 0;
+    unsigned long long* h_sum = nullptr;      // pinned
+    LookAhead slot[2];
+    size_t slot_floats = 0;
+    int last_counter = 0, streak = 0, calls_since_check = 0;
+    Camera last_cam;
     bool have_last = false;
 } g_launch;
 
@@ -1138,13 +1151,39 @@ bool same_camera(const Camera& a, const Camera& b) {
     fprintf(stderr, "%s %s\n", what, g_error.c_str());
     exit(EXIT_FAILURE);
 }
+void hip_or_die(hipError_t e, const char* what) {
+    if (e != hipSuccess) { g_error = std::string(what) + ": " + hipGetErrorString(e); die("launchKernel:"); }
+}
+
+void drop_lookahead(LaunchCache& L, bool free_buffers) {
+    for (LookAhead& a : L.slot) {
+        a.count = 0;
+        if (free_buffers && a.d_img3) { (void)hipFree(a.d_img3); a.d_img3 = nullptr; }
+    }
+    if (free_buffers) L.slot_floats = 0;
+}
+
+// How often a run of calls with consecutive counters re-reads the scene arrays to see whether the
+// caller changed them behind unchanged pointers (every call outside such a run does).
+const int kChecksumEvery = 16;
 }  // namespace
 
 void gpt_launch_kernel_params(const gpt_render_params* params) {
     std::lock_guard<std::mutex> lock(g_launch.mu);
     if (params) { g_launch.params = *params; g_launch.params_set = true; }
     else g_launch.params_set = false;
-    if (g_launch.scene) { gpt_scene_destroy(g_launch.scene); g_launch.scene = nullptr; }
+    if (g_launch.scene) {
+        DeviceGuard guard(g_launch.scene->device);
+        (void)hipStreamSynchronize(g_launch.scene->stream);
+        drop_lookahead(g_launch, true);
+        gpt_scene_destroy(g_launch.scene);
+        g_launch.scene = nullptr;
+    }
+}
+
+void gpt_launch_kernel_static_scene(int is_static) {
+    std::lock_guard<std::mutex> lock(g_launch.mu);
+    g_launch.assume_static = is_static != 0;
 }
 
 void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, int numPixels, Color* pixels,
@@ -1153,28 +1192,50 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
     LaunchCache& L = g_launch;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { g_error = "no HIP device"; die("launchKernel:"); }
-    // content checksum of the two device arrays: the scene is re-indexed only when it changes
-    if (!L.d_sum && hipMalloc((void**)&L.d_sum, 8) != hipSuccess) { g_error = "hipMalloc"; die("launchKernel:"); }
-    unsigned long long sum = 0;
-    if (hipMemset(L.d_sum, 0, 8) != hipSuccess) { g_error = "hipMemset"; die("launchKernel:"); }
-    if (numPolys > 0) gptk_checksum(nullptr, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
-    if (numSpheres > 0) gptk_checksum(nullptr, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);
-    if (hipMemcpy(&sum, L.d_sum, 8, hipMemcpyDeviceToHost) != hipSuccess) {
-        g_error = hipGetErrorString(hipGetLastError());
-        die("launchKernel: checksum failed:");
+    if (L.device != dev) {
+        // first call (or the caller moved to another GPU): the side stream and the checksum words live on `dev`
+        if (L.scene) {
+            DeviceGuard guard(L.scene->device);
+            (void)hipStreamSynchronize(L.scene->stream);
+            drop_lookahead(L, true);
+            gpt_scene_destroy(L.scene);
+            L.scene = nullptr;
+        }
+        hip_or_die(hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking), "stream");
+        hip_or_die(hipMalloc((void**)&L.d_sum, 8), "hipMalloc");
+        hip_or_die(hipHostMalloc((void**)&L.h_sum, 8, hipHostMallocDefault), "hipHostMalloc");
+        for (LookAhead& a : L.slot) hip_or_die(hipEventCreateWithFlags(&a.done, hipEventDisableTiming), "event");
+        L.device = dev;
     }
-    const bool same = L.scene && L.polys == polys && L.spheres == spheres && L.numPolys == numPolys &&
-                      L.numSpheres == numSpheres && L.checksum == sum;
+    const bool same_arrays = L.scene && L.polys == polys && L.spheres == spheres && L.numPolys == numPolys && L.numSpheres == numSpheres;
+    const bool continues = L.have_last && same_camera(L.last_cam, renderCamera) && counter == L.last_counter + 1;
+    // Content checksum of the two device arrays: the scene is re-indexed only when it changes.  It runs on the
+    // side stream (the caller's own streams are not touched), on every call that does not continue a run of
+    // consecutive counters and on every kChecksumEvery-th call of such a run -- or never again once the
+    // caller has declared the scene static.
+    bool same = same_arrays;
+    if (!same_arrays || (!L.assume_static && (!continues || ++L.calls_since_check >= kChecksumEvery))) {
+        L.calls_since_check = 0;
+        hip_or_die(hipMemsetAsync(L.d_sum, 0, 8, L.copy), "hipMemset");
+        if (numPolys > 0) gptk_checksum(L.copy, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
+        if (numSpheres > 0) gptk_checksum(L.copy, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);
+        hip_or_die(hipMemcpyAsync(L.h_sum, L.d_sum, 8, hipMemcpyDeviceToHost, L.copy), "checksum readback");
+        hip_or_die(hipStreamSynchronize(L.copy), "checksum");
+        same = same_arrays && L.checksum == *L.h_sum;
+    }
     if (!same) {
-        if (L.scene) { gpt_scene_destroy(L.scene); L.scene = nullptr; }
+        const unsigned long long sum = *L.h_sum;
+        if (L.scene) {
+            DeviceGuard guard(L.scene->device);
+            (void)hipStreamSynchronize(L.scene->stream);
+            drop_lookahead(L, true);
+            gpt_scene_destroy(L.scene);
+            L.scene = nullptr;
+        }
         std::vector<Poly> hp((size_t)std::max(numPolys, 0));
         std::vector<Sphere> hs((size_t)std::max(numSpheres, 0));
-        if (numPolys > 0 && hipMemcpy(hp.data(), polys, hp.size() * sizeof(Poly), hipMemcpyDeviceToHost) != hipSuccess) {
-            g_error = "copying polys from the device failed"; die("launchKernel:");
-        }
-        if (numSpheres > 0 && hipMemcpy(hs.data(), spheres, hs.size() * sizeof(Sphere), hipMemcpyDeviceToHost) != hipSuccess) {
-            g_error = "copying spheres from the device failed"; die("launchKernel:");
-        }
+        if (numPolys > 0) hip_or_die(hipMemcpy(hp.data(), polys, hp.size() * sizeof(Poly), hipMemcpyDeviceToHost), "copying polys from the device");
+        if (numSpheres > 0) hip_or_die(hipMemcpy(hs.data(), spheres, hs.size() * sizeof(Sphere), hipMemcpyDeviceToHost), "copying spheres from the device");
         gpt_render_params rp;
         if (L.params_set) rp = L.params;
         else { gpt_render_params_default(&rp); rp.row_stride_is_width = 0; }   // the reference's arithmetic
@@ -1183,45 +1244,57 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         if (gpt_scene_create(hs.data(), numSpheres, hp.data(), numPolys, &rp, dev, &L.scene) != GPT_OK)
             die("launchKernel: scene upload failed:");
         L.polys = polys; L.spheres = spheres; L.numPolys = numPolys; L.numSpheres = numSpheres; L.checksum = sum;
-        L.ahead_count = 0;
         L.have_last = false;
     }
     gpt_scene* s = L.scene;
+    DeviceGuard device_guard_(s->device);
+    if (!device_guard_.ok()) { g_error = "hipSetDevice"; die("launchKernel:"); }
     if (s->numPixels != numPixels) {
+        hip_or_die(hipStreamSynchronize(s->stream), "sync");
+        drop_lookahead(L, true);
         if (gpt_scene_reset(s, numPixels) != GPT_OK) die("launchKernel: buffer allocation failed:");
-        L.ahead_count = 0;
     }
     if (check_render_args(s, &renderCamera) != GPT_OK) die("launchKernel:");
+    const size_t pass_floats = (size_t)numPixels * 3;
+    if (L.slot_floats != pass_floats * (size_t)s->batch) {
+        drop_lookahead(L, true);
+        for (LookAhead& a : L.slot) hip_or_die(hipMalloc((void**)&a.d_img3, pass_floats * (size_t)s->batch * sizeof(float)), "look-ahead buffer");
+        L.slot_floats = pass_floats * (size_t)s->batch;
+    }
     // The reference's render loop asks for counter, counter + 1, ... with an unchanged camera until
     // the user moves it (path_tracer.cpp:94-108).  A pass is a pure function of (scene, camera,
     // counter), and tracing passes one at a time pays the tail of the longest paths at every depth,
-    // so a run of such calls is answered from batches traced ahead: 1, 2, 4, ... passes (at most the
-    // scene's passes_in_flight) while the run lasts; any other call starts over with a single pass.
-    const bool in_cache = L.ahead_count > 0 && same_camera(L.cam, renderCamera) && counter >= L.ahead_begin &&
-                          counter - L.ahead_begin < L.ahead_count;
-    const bool continues = L.have_last && same_camera(L.cam, renderCamera) && counter == L.last_counter + 1;
+    // so a run of such calls is answered from batches traced ahead -- 1, 2, 4, ... passes, at most the
+    // scene's passes_in_flight -- into one of two buffers: while the caller takes the passes of one
+    // (a plain device-to-host copy on the side stream), the next batch is already being traced into the
+    // other.  Any other call (camera moved, counter jumped) starts over with a single pass.
     L.streak = continues ? L.streak + 1 : 0;
-    DeviceGuard device_guard_(s->device);
-    if (!device_guard_.ok()) { g_error = "hipSetDevice"; die("launchKernel:"); }
-    if (!in_cache) {
+    auto holds = [&](const LookAhead& a, int c) { return a.count > 0 && same_camera(a.cam, renderCamera) && c >= a.begin && c - a.begin < a.count; };
+    auto trace_into = [&](LookAhead& a, int begin, int P) {
+        if (enqueue_batch(s, &renderCamera, begin, P, a.d_img3) != GPT_OK) die("launchKernel:");
+        hip_or_die(hipEventRecord(a.done, s->stream), "event");
+        a.cam = renderCamera; a.begin = begin; a.count = P;
+    };
+    int cur = holds(L.slot[0], counter) ? 0 : (holds(L.slot[1], counter) ? 1 : -1);
+    if (cur < 0) {
         int P = 1;
         for (int k = 0; k < L.streak && P < s->batch; k++) P *= 2;
-        P = std::min(P, s->batch);
-        if (enqueue_batch(s, &renderCamera, counter, P, nullptr) != GPT_OK) die("launchKernel:");
-        L.cam = renderCamera;
-        L.ahead_begin = counter;
-        L.ahead_count = P;
+        // (the buffer that does not hold the previous call's batch, so that a run's prefetched batch survives)
+        cur = (L.have_last && holds(L.slot[0], L.last_counter)) ? 1 : 0;
+        trace_into(L.slot[cur], counter, std::min(P, s->batch));
     }
+    LookAhead& A = L.slot[cur];
+    hip_or_die(hipStreamWaitEvent(L.copy, A.done, 0), "wait");
+    hip_or_die(hipMemcpyAsync(pixels, A.d_img3 + (size_t)(counter - A.begin) * pass_floats, pass_floats * sizeof(float),
+                              hipMemcpyDeviceToHost, L.copy), "device-to-host copy");
+    // while that copy runs: the batch after this one, once the run is established
+    LookAhead& B = L.slot[cur ^ 1];
+    const int next_begin = A.begin + A.count;
+    if (L.streak >= 2 && s->batch > 1 && !holds(B, next_begin)) trace_into(B, next_begin, std::min(s->batch, std::max(2 * A.count, 2)));
+    hip_or_die(hipStreamSynchronize(L.copy), "device-to-host copy");
     L.last_counter = counter;
+    L.last_cam = renderCamera;
     L.have_last = true;
-    gptk_extract_pass(s->stream, pixel_grid(numPixels), numPixels, L.ahead_count, counter - L.ahead_begin, s->d_pass, s->d_pass3);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(pixels, s->d_pass3, (size_t)numPixels * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-        hipStreamSynchronize(s->stream) != hipSuccess) {
-        g_error = hipGetErrorString(hipGetLastError());
-        die("launchKernel:");
-    }
-    if (collect_events(s) != GPT_OK) die("launchKernel:");
 }
 
 }  // extern "C"

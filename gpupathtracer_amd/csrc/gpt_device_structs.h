@@ -30,7 +30,7 @@
 #define GPT_STAT_WORDS (3 * GPT_MAX_DEPTH + 8)
 
 struct DevGeometry {
-    const float4* spheres;     // (centre.xyz, radius)
+    const float4* spheres;     // (centre.xyz, radius * radius)
     const int* sphere_mat;     // material index per sphere
     int n_spheres;
     int n_tris;

@@ -124,7 +124,7 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
     const int n = g.n_spheres;
     for (int s = 0; s < n; s++) {
         const cf4 sp = sph[s];
-        if (sphere_closer(v3(sp.x, sp.y, sp.z), sp.w, o, d, bestT)) prim = PT_PRIM_SPHERE | s;
+        if (sphere_closer(v3(sp.x, sp.y, sp.z), sp.w /* radius^2 */, o, d, bestT)) prim = PT_PRIM_SPHERE | s;
     }
     bestT_out = bestT;
     prim_out = prim;
@@ -155,8 +155,9 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
         camera_ray(cam, pixel, seed0 + pass, o, d);
         st_stream(&ray_o[i], make_float4(o.x, o.y, o.z, __int_as_float(pixel)));
         st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
-        // (no throughput is stored for a primary ray: see k_shade<true>)
-        st_stream(&pass_rgb[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        // (no throughput is stored for a primary ray, and its pass radiance slot is not cleared here:
+        // k_shade<true> handles every slot of the uncompacted queue exactly once and starts the slot with
+        // what the first bounce adds, or zero)
         float bestT;
         int prim;
         analytic_hits(g, o, d, bestT, prim);
@@ -657,7 +658,12 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
                 dbg_events[(size_t)pixel * (size_t)dbg_stride + (size_t)depth] = (unsigned char)event;
                 dbg_prims[(size_t)pixel * (size_t)dbg_stride + (size_t)depth] = prim;
             }
-            if (has_add) {
+            if (FIRST) {
+                // slot i of the uncompacted queue IS (pixel, pass): the first bounce stores 0 + add (the sum spelled
+                // out: it turns a -0 into the +0 the reference's accumulator would hold) instead of read-modify-write
+                st_stream(&pass_rgb[i], has_add ? make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 0.0f)
+                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            } else if (has_add) {
                 const size_t slot = (size_t)pixel * (size_t)numPasses + (size_t)pass;
                 float4 acc = pass_rgb[slot];
                 acc.x += add.x; acc.y += add.y; acc.z += add.z;
@@ -719,8 +725,9 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
 // ---------------------------------------------------------------------------
 // k_finish: image += pass for every pass of the batch, in counter order, so a
 // pixel's float sum is the one PathTracer::render builds (path_tracer.cpp:100-103).
-// Optionally the (single) pass alone as packed float3 for the host (the
-// reference's D2H copy, path_tracer_kernel.cu:869).
+// Optionally every pass of the batch on its own as packed float3, pass after pass
+// (pass k at pass_out3 + k * 3 * numPixels): what the reference's D2H copy hands
+// to the host per pass (path_tracer_kernel.cu:869).
 // ---------------------------------------------------------------------------
 // A pixel's P pass values lie next to each other (16 P bytes), so a thread that walked its own
 // pixel's row would fetch one cache line per lane and load.  Instead the block stages tiles of
@@ -750,16 +757,20 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_finish(int numPixels, int numPass
                     p = s_tile[t][k];
                     a.x += p.x; a.y += p.y; a.z += p.z; a.w += 1.0f;
                 }
+            if (pass_out3) {
+                // all 256 threads: pass k of the tile's 64 pixels is 192 consecutive floats of the output
+                for (int e = t; e < kn * FIN_PIXELS * 3; e += GPT_BLOCK) {
+                    const int k = e / (FIN_PIXELS * 3), w = e - k * (FIN_PIXELS * 3), r = w / 3, ch = w - 3 * r;
+                    if (pix0 + r < numPixels) {
+                        const float4 v = s_tile[r][k];
+                        pass_out3[(size_t)(k0 + k) * 3 * (size_t)numPixels + 3 * (size_t)(pix0 + r) + (size_t)ch] =
+                            ch == 0 ? v.x : (ch == 1 ? v.y : v.z);
+                    }
+                }
+            }
             __syncthreads();
         }
-        if (owner) {
-            image[i] = a;
-            if (pass_out3) {
-                pass_out3[3 * (size_t)i + 0] = p.x;
-                pass_out3[3 * (size_t)i + 1] = p.y;
-                pass_out3[3 * (size_t)i + 2] = p.z;
-            }
-        }
+        if (owner) image[i] = a;
     }
 }
 

@@ -42,11 +42,58 @@ PT_HD V3 cross(V3 a, V3 b) {
 PT_HD float length(V3 v) { return sqrtf(dot(v, v)); }
 PT_HD V3 normalize(V3 v) { float invLen = 1.0f / sqrtf(dot(v, v)); return v * invLen; }
 
-// ---- transcendental policy: double, rounded once -------------------------
+// ---- transcendental policy ---------------------------------------------------
+// sin / cos of the angles the path tracer forms, TWO_PI * xi in [0, 2 pi]: the algorithm of the
+// host C library's sinf / cosf (glibc 2.28 and later: reduction by multiples of pi/2 and two short
+// polynomials, all in double, one rounding to float at the end), restated operation for operation.
+// Compared exhaustively with sinf / cosf for every float in [0, 6.2831855] (1 086 918 620 values):
+// identical bits, with and without fused multiply-add in the polynomials.  So the device takes
+// exactly the values a host build of the reference gets from its libm -- and at a third of the
+// instructions of a full double-precision sincos.  Host builds send any other argument to double
+// sincos rounded once; device code has no such path (every caller passes TWO_PI * xi with xi in
+// [0, 1], and a second, never-taken copy of sincos would only cost registers and code size).
 PT_HD void sincos_f(float a, float& s, float& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+#else
+    if (a >= 0.0f && a <= 6.2831855f) {
+#endif
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                     C4 = 0x1.99343027bf8c3p-16;
+        const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+        double x = (double)a;
+        int n = 0;
+        if (!(a < 0.75f)) {                      // below 0.75 (the library's top-12-bit test against pi/4): no reduction
+            const double r = x * hpi_inv;
+            n = ((int32_t)r + 0x800000) >> 24;   // nearest multiple of pi/2
+            x = x - (double)n * hpi;
+        }
+        const double x2 = x * x;
+        const double xs = ((n + 1) & 2) ? -x : x;           // sign of the sine in quadrants 0..3: + - - +
+        // sine polynomial of the reduced argument
+        const double x3 = xs * x2;
+        const double s1 = S2 + x2 * S3;
+        const double x7 = x3 * x2;
+        const double sp0 = xs + x3 * S1;
+        const float SP = (float)(sp0 + x7 * s1);
+        // cosine polynomial; in quadrants 2 and 3 the library negates every coefficient, which negates the result exactly
+        const double x4 = x2 * x2;
+        const double c2 = C3 + x2 * C4;
+        const double c1 = C0 + x2 * C1;
+        const double x6 = x4 * x2;
+        const double cp0 = c1 + x4 * C2;
+        float CP = (float)(cp0 + x6 * c2);
+        if (n & 2) CP = -CP;
+        if (n & 1) { s = CP; c = SP; } else { s = SP; c = CP; }
+        if (a < 0x1p-12f) { s = a; c = 1.0f; }
+        return;
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
     double sd, cd;
     ::sincos((double)a, &sd, &cd);
     s = (float)sd; c = (float)cd;
+#endif
 }
 PT_HD float log_f(float x) { return (float)::log((double)x); }
 // pow((float)E, y) of path_tracer_kernel.cu:471-473: E narrowed to float, so the
@@ -185,10 +232,12 @@ PT_HD float sphere_t(V3 center, float radius, V3 o, V3 d) {
 // The caller's loop around sphere_t (:521-533): true, and bestT lowered, when this sphere's t
 // satisfies 0 < t < bestT.  Same arithmetic as sphere_t; everything after the radicand test sits
 // in one branch, which a wave skips altogether when none of its rays' lines meets the sphere.
-PT_HD bool sphere_closer(V3 center, float radius, V3 o, V3 d, float& bestT) {
+// `radius2` is radius * radius, formed once per sphere instead of once per test (one float
+// multiplication either way: the same bits).
+PT_HD bool sphere_closer(V3 center, float radius2, V3 o, V3 d, float& bestT) {
     V3 v = o - center;
     float vDotDirection = dot(v, d);
-    float radicand = vDotDirection * vDotDirection - (dot(v, v) - radius * radius);
+    float radicand = vDotDirection * vDotDirection - (dot(v, v) - radius2);
     bool closer = false;
     if (radicand >= 0) {            // (a NaN radicand ends without a hit in sphere_t as well)
         float squareRoot = sqrtf(radicand);

@@ -339,8 +339,11 @@ void       gpt_kdtree_free(gpt_kdtree* tree);
 /* gpt_launch_kernel_params().  Errors: message on stderr + exit(1).           */
 /* A run of calls with consecutive counters and an unchanged camera (the       */
 /* reference's render loop, path_tracer.cpp:94-108) is served from batches of  */
-/* up to passes_in_flight passes (32 by default here) traced ahead and kept on */
-/* the device; each call still returns exactly the pass `counter` names.       */
+/* up to passes_in_flight passes (32 by default here) traced ahead into two    */
+/* device buffers -- one being handed out, the next being traced -- and each    */
+/* call still returns exactly the pass `counter` names.  The arrays' contents   */
+/* are checksummed on every call outside such a run and on every 16th call      */
+/* inside one.                                                                  */
 /* ------------------------------------------------------------------------- */
 #ifndef GPT_NO_POD_TYPES
 void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres,
@@ -348,6 +351,10 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres,
 #endif
 /* Parameters used by subsequent launchKernel calls (NULL restores defaults). */
 void gpt_launch_kernel_params(const gpt_render_params* params);
+/* Non-zero: the caller promises not to change the contents of the arrays behind
+ * an unchanged (pointer, count) pair (the reference uploads its scene once,
+ * path_tracer.cpp:281-284): launchKernel stops re-reading them. */
+void gpt_launch_kernel_static_scene(int is_static);
 /* Device-memory helpers for callers of launchKernel that have no HIP runtime
  * of their own (the reference used cudaMalloc/cudaMemcpy/cudaFree). */
 gpt_status gpt_device_alloc(void** out_ptr, size_t bytes);

@@ -194,6 +194,25 @@ int64_t hh_render_pass(void* tree_or_null, int numPolys, const Poly* polys, int 
     return total;
 }
 
+// pt::sincos_f against the C library's sinf / cosf for the floats with bit patterns first, first + step, ... <= last:
+// returns the number of arguments for which either result differs in any bit.
+long long hh_sincos_mismatches(uint32_t first, uint32_t last, uint32_t step) {
+    long long bad = 0;
+    const long long n = ((long long)last - (long long)first) / (long long)step + 1;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long k = 0; k < n; k++) {
+        const uint32_t u = first + (uint32_t)(k * step);
+        float a;
+        memcpy(&a, &u, 4);
+        float s, c;
+        pt::sincos_f(a, s, c);
+        volatile float av = a;
+        const float gs = sinf(av), gc = cosf(av);
+        if (memcmp(&s, &gs, 4) != 0 || memcmp(&c, &gc, 4) != 0) bad++;
+    }
+    return bad;
+}
+
 // pt::Rng (the generator the kernels use), host build: n_draws uniforms per seed
 void hh_rng_uniforms(const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
     for (int s = 0; s < n_seeds; s++) {

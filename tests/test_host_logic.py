@@ -105,3 +105,12 @@ def test_mesh_scene_logic_parity_kd_and_brute(H):
     rel = (np.abs(a - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=1)
     assert (rel > 1e-4).mean() < 4e-3
     assert ((fpa >= 0) & (fpa < polys.size)).sum() > 50
+
+
+def test_sincos_is_the_c_librarys_bit_for_bit(H):
+    """pt::sincos_f (what the kernels call for lens, diffuse and scatter directions) restates the C library's
+    sinf / cosf algorithm: identical bits for EVERY float of the range the renderer uses, [0, 2 pi]."""
+    H.hh_sincos_mismatches.restype = ctypes.c_longlong
+    H.hh_sincos_mismatches.argtypes = [ctypes.c_uint32] * 3
+    two_pi_bits = int(np.array([6.2831855], np.float32).view(np.uint32)[0])
+    assert H.hh_sincos_mismatches(0, two_pi_bits, 1) == 0

@@ -22,4 +22,11 @@ for c in range(1, 1 + n):
     api.launch_kernel(polys.size, d_p, spheres.size, d_s, w * h, c, cam)
 dt = time.perf_counter() - t0
 print("passes_in_flight %d: %d calls, %.2f ms per call (incl. the 24.9 MB device-to-host copy)" % (lookahead, n, dt / n * 1e3))
+times = []
+for c in range(1 + n, 1 + 2 * n):
+    t1 = time.perf_counter()
+    api.launch_kernel(polys.size, d_p, spheres.size, d_s, w * h, c, cam)
+    times.append((time.perf_counter() - t1) * 1e3)
+times = np.array(times)
+print("per call: mean %.2f ms, median %.2f, 95th percentile %.2f, max %.2f" % (times.mean(), np.median(times), np.percentile(times, 95), times.max()))
 api.launch_kernel_params(None)
