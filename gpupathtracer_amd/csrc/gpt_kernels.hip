@@ -454,6 +454,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             // the lanes' conditions are kept as wave masks (KdPred): the loop's control logic then
             // runs on the scalar unit, and the only divergent regions are the node load and the push
             const KdPred walkM = haveM & ~parkedM;
+#ifdef ABL_WALK_PAD   // experiment: ABL_WALK_PAD extra vector instructions per walk iteration (is the loop VALU-bound?)
+            {
+                unsigned pad_ = lane;
+#pragma unroll
+                for (int q_ = 0; q_ < ABL_WALK_PAD; q_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_));
+            }
+#endif
             if (walkM.on()) {
                 if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
                 w = g.kd.nodes[cur.node];
@@ -497,6 +504,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned r0u = unit * p + (unsigned)bperm(la, (int)(leafFirst - unit * excl));
                 const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
                 const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
+#ifdef ABL_TRI_PAD
+                {
+                    unsigned pad_ = lane;
+#pragma unroll
+                    for (int q_ = 0; q_ < ABL_TRI_PAD; q_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_));
+                }
+#endif
                 if (p < total) {
                     const float* rp = packed ? reinterpret_cast<const float*>(g.kd.leaf_tris) + 2 * (size_t)r0u
                                              : g.kd.leaf_tris[g.kd.refs[r0u]].f;
@@ -553,14 +567,17 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 4
 #endif
-#define SHADE_STAGE (SHADE_FLUSH + GPT_BLOCK)
+#ifndef SHADE_BLOCK
+#define SHADE_BLOCK 256   // threads per workgroup of k_shade
+#endif
+#define SHADE_STAGE (SHADE_FLUSH + SHADE_BLOCK)
 
 // FIRST: the launch that shades the primary rays.  k_camera stores no throughput for them: it is (1, 1, 1),
 // and slot i of the still uncompacted queue belongs to pass i - pixel * numPasses.
 // DEBUG: every bounce's branch code (PT_EV_*) and primitive go to dbg_events / dbg_prims at
 // [pixel * dbg_stride + depth] (single-pass launches only; parity checks read them).
 template <bool FIRST, bool DEBUG>
-__global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
                                                      int numPasses,
                                                      const float4* __restrict__ in_o,
                                                      const float4* __restrict__ in_d,
@@ -578,7 +595,7 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
     __shared__ float4 s_o[SHADE_STAGE];
     __shared__ float4 s_d[SHADE_STAGE];
     __shared__ float4 s_t[SHADE_STAGE];
-    __shared__ unsigned s_wave_cnt[GPT_BLOCK / 64];
+    __shared__ unsigned s_wave_cnt[SHADE_BLOCK / 64];
     __shared__ unsigned s_base;
 
     const unsigned n = counts[depth];
@@ -597,8 +614,8 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
         st_stream(&out_hit[pos], make_float2(bestT, __int_as_float(prim)));
     };
     unsigned staged = 0;                        // block-uniform: survivors waiting in LDS
-    const unsigned stride = gridDim.x * GPT_BLOCK;
-    for (unsigned tile = blockIdx.x * GPT_BLOCK; tile < n; tile += stride) {
+    const unsigned stride = gridDim.x * SHADE_BLOCK;
+    for (unsigned tile = blockIdx.x * SHADE_BLOCK; tile < n; tile += stride) {
         const unsigned i = tile + threadIdx.x;
         bool alive = false;
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0), thr = v3(0, 0, 0);
@@ -676,7 +693,7 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
         __syncthreads();
         unsigned before = 0, total = 0;
 #pragma unroll
-        for (unsigned w = 0; w < GPT_BLOCK / 64; w++) {
+        for (unsigned w = 0; w < SHADE_BLOCK / 64; w++) {
             const unsigned c = s_wave_cnt[w];
             if (w < wave) before += c;
             total += c;
@@ -694,8 +711,8 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
             __syncthreads();
             const unsigned base = s_base;
 #pragma unroll
-            for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += GPT_BLOCK) emit(base + k, k);
-            // move the remainder (< 256 entries) to the front
+            for (unsigned k = threadIdx.x; k < SHADE_FLUSH; k += SHADE_BLOCK) emit(base + k, k);
+            // move the remainder (fewer entries than the block has threads) to the front
             const unsigned rem = staged - SHADE_FLUSH;
             float4 ko = make_float4(0, 0, 0, 0), kd_ = ko, kt = ko;
             if (threadIdx.x < rem) {
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(GPT_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeom
         if (threadIdx.x == 0) s_base = atomicAdd(&counts[depth + 1], staged);
         __syncthreads();
         const unsigned base = s_base;
-        for (unsigned k = threadIdx.x; k < staged; k += GPT_BLOCK) emit(base + k, k);
+        for (unsigned k = threadIdx.x; k < staged; k += SHADE_BLOCK) emit(base + k, k);
     }
 }
 
@@ -873,9 +890,10 @@ void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
                 unsigned long long* stats, unsigned char* dbg_events, int* dbg_prims, int dbg_stride) {
 #define GPT_LAUNCH_SHADE(FIRST, DEBUG)                                                                                       \
-    hipLaunchKernelGGL((k_shade<FIRST, DEBUG>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, \
+    hipLaunchKernelGGL((k_shade<FIRST, DEBUG>), dim3(blocks), dim3(SHADE_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, \
                        in_thr, hit, out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats, dbg_events, dbg_prims, dbg_stride)
     const bool debug = dbg_events != nullptr && dbg_prims != nullptr;
+    const int blocks = grid * GPT_BLOCK / SHADE_BLOCK > 0 ? grid * GPT_BLOCK / SHADE_BLOCK : 1;   // `grid` counts 256-thread blocks
     if (depth == 0) { if (debug) GPT_LAUNCH_SHADE(true, true); else GPT_LAUNCH_SHADE(true, false); }
     else { if (debug) GPT_LAUNCH_SHADE(false, true); else GPT_LAUNCH_SHADE(false, false); }
 #undef GPT_LAUNCH_SHADE

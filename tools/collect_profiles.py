@@ -54,6 +54,30 @@ for line in open(os.path.join(src, "trace.log"), errors="replace"):
         shutil.copy(os.path.join(src, "trace.log"), os.path.join(out, tag + "_bench_under_trace.log"))
 derived["path_bounces_per_launch"] = pb_per_launch
 d["derived_k_intersect_kd"] = derived
+
+
+def per_kernel(name):
+    """HBM-side bytes over kernel time, VALU issue-slot occupancy and lane activity of one kernel (all its dispatches)."""
+    keys = [k for k in d["counters"] if name in k]
+    if not keys:
+        return None
+    c = d["counters"][keys[0]]
+    t_us = d["kernels"][keys[0]]["total_us"]
+    rd = 32 * c["TCC_EA0_RDREQ_32B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c["TCC_EA0_RDREQ_128B_sum"]
+    wr = c["WRITE_SIZE"] * 1024
+    return {
+        "kernel": keys[0], "dispatches": c["_dispatches"]["pmc_sq"], "total_ms_traced": t_us / 1e3,
+        "hbm_read_gb": rd / 1e9, "hbm_write_gb": wr / 1e9, "hbm_tb_per_s": (rd + wr) / 1e12 / (t_us / 1e6),
+        "hbm_frac_of_8tb": (rd + wr) / 1e12 / (t_us / 1e6) / 8.0,
+        "l2_hit_rate": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+        "valu_busy": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+        "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+        "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+        "valu_wave_insts": c["SQ_INSTS_VALU"], "salu_wave_insts": c["SQ_INSTS_SALU"],
+    }
+
+
+d["derived_per_kernel"] = {n: per_kernel(n) for n in ("k_intersect_kd<false>", "k_shade", "k_camera", "k_finish")}
 json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
 json.dump({
     "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
