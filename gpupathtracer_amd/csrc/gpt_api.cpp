@@ -1120,6 +1120,15 @@ struct LookAhead {
     int begin = 0, count = 0;     // counters [begin, begin + count); count == 0: empty
     hipEvent_t done = nullptr;    // recorded behind the batch on the scene's stream
 };
+// One pass on its way to the host: pinned staging buffer + the event behind its copy.
+struct Staged {
+    float* host = nullptr;        // pinned, numPixels x 3 floats
+    hipEvent_t done = nullptr;
+    Camera cam;
+    int counter = 0;
+    int src_slot = -1;            // the look-ahead buffer the copy reads (until `done`)
+    bool valid = false;
+};
 struct LaunchCache {
     std::mutex mu;
     gpt_scene* scene = nullptr;
@@ -1134,6 +1143,7 @@ struct LaunchCache {
     unsigned long long* d_sum = nullptr;
     unsigned long long* h_sum = nullptr;      // pinned
     LookAhead slot[2];
+    Staged staged[2];
     size_t slot_floats = 0;
     int last_counter = 0, streak = 0, calls_since_check = 0;
     Camera last_cam;
@@ -1156,6 +1166,11 @@ void hip_or_die(hipError_t e, const char* what) {
 }
 
 void drop_lookahead(LaunchCache& L, bool free_buffers) {
+    if (L.copy) (void)hipStreamSynchronize(L.copy);
+    for (Staged& st : L.staged) {
+        st.valid = false; st.src_slot = -1;
+        if (free_buffers && st.host) { (void)hipHostFree(st.host); st.host = nullptr; }
+    }
     for (LookAhead& a : L.slot) {
         a.count = 0;
         if (free_buffers && a.d_img3) { (void)hipFree(a.d_img3); a.d_img3 = nullptr; }
@@ -1205,6 +1220,7 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         hip_or_die(hipMalloc((void**)&L.d_sum, 8), "hipMalloc");
         hip_or_die(hipHostMalloc((void**)&L.h_sum, 8, hipHostMallocDefault), "hipHostMalloc");
         for (LookAhead& a : L.slot) hip_or_die(hipEventCreateWithFlags(&a.done, hipEventDisableTiming), "event");
+        for (Staged& st : L.staged) hip_or_die(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "event");
         L.device = dev;
     }
     const bool same_arrays = L.scene && L.polys == polys && L.spheres == spheres && L.numPolys == numPolys && L.numSpheres == numSpheres;
@@ -1259,15 +1275,16 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
     if (L.slot_floats != pass_floats * (size_t)s->batch) {
         drop_lookahead(L, true);
         for (LookAhead& a : L.slot) hip_or_die(hipMalloc((void**)&a.d_img3, pass_floats * (size_t)s->batch * sizeof(float)), "look-ahead buffer");
+        for (Staged& st : L.staged) hip_or_die(hipHostMalloc((void**)&st.host, pass_floats * sizeof(float), hipHostMallocDefault), "staging buffer");
         L.slot_floats = pass_floats * (size_t)s->batch;
     }
     // The reference's render loop asks for counter, counter + 1, ... with an unchanged camera until
     // the user moves it (path_tracer.cpp:94-108).  A pass is a pure function of (scene, camera,
     // counter), and tracing passes one at a time pays the tail of the longest paths at every depth,
     // so a run of such calls is answered from batches traced ahead -- 1, 2, 4, ... passes, at most the
-    // scene's passes_in_flight -- into one of two buffers: while the caller takes the passes of one
-    // (a plain device-to-host copy on the side stream), the next batch is already being traced into the
-    // other.  Any other call (camera moved, counter jumped) starts over with a single pass.
+    // scene's passes_in_flight -- into one of two buffers: while the caller takes the passes of one,
+    // the next batch is already being traced into the other.  Any other call (camera moved, counter
+    // jumped) starts over with a single pass.
     L.streak = continues ? L.streak + 1 : 0;
     auto holds = [&](const LookAhead& a, int c) { return a.count > 0 && same_camera(a.cam, renderCamera) && c >= a.begin && c - a.begin < a.count; };
     auto trace_into = [&](LookAhead& a, int begin, int P) {
@@ -1275,23 +1292,47 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         hip_or_die(hipEventRecord(a.done, s->stream), "event");
         a.cam = renderCamera; a.begin = begin; a.count = P;
     };
+    // Before a buffer is traced into again, no copy may still be reading it.
+    auto trace_over = [&](int k, int begin, int P) {
+        for (Staged& st : L.staged)
+            if (st.valid && st.src_slot == k) { hip_or_die(hipEventSynchronize(st.done), "copy"); st.src_slot = -1; }
+        trace_into(L.slot[k], begin, P);
+    };
     int cur = holds(L.slot[0], counter) ? 0 : (holds(L.slot[1], counter) ? 1 : -1);
     if (cur < 0) {
         int P = 1;
         for (int k = 0; k < L.streak && P < s->batch; k++) P *= 2;
         // (the buffer that does not hold the previous call's batch, so that a run's prefetched batch survives)
         cur = (L.have_last && holds(L.slot[0], L.last_counter)) ? 1 : 0;
-        trace_into(L.slot[cur], counter, std::min(P, s->batch));
+        trace_over(cur, counter, std::min(P, s->batch));
     }
-    LookAhead& A = L.slot[cur];
-    hip_or_die(hipStreamWaitEvent(L.copy, A.done, 0), "wait");
-    hip_or_die(hipMemcpyAsync(pixels, A.d_img3 + (size_t)(counter - A.begin) * pass_floats, pass_floats * sizeof(float),
-                              hipMemcpyDeviceToHost, L.copy), "device-to-host copy");
-    // while that copy runs: the batch after this one, once the run is established
-    LookAhead& B = L.slot[cur ^ 1];
-    const int next_begin = A.begin + A.count;
-    if (L.streak >= 2 && s->batch > 1 && !holds(B, next_begin)) trace_into(B, next_begin, std::min(s->batch, std::max(2 * A.count, 2)));
-    hip_or_die(hipStreamSynchronize(L.copy), "device-to-host copy");
+    // The pass travels device -> pinned staging buffer (a DMA on the side stream) -> caller's buffer (a host copy):
+    // faster than a copy straight into pageable memory, and the DMA of the NEXT pass is started before this call
+    // returns, so that a run of calls finds its pass already on the host.
+    auto stage = [&](Staged& st, int k, int c) {
+        const LookAhead& a = L.slot[k];
+        hip_or_die(hipStreamWaitEvent(L.copy, a.done, 0), "wait");
+        hip_or_die(hipMemcpyAsync(st.host, a.d_img3 + (size_t)(c - a.begin) * pass_floats, pass_floats * sizeof(float),
+                                  hipMemcpyDeviceToHost, L.copy), "device-to-host copy");
+        hip_or_die(hipEventRecord(st.done, L.copy), "event");
+        st.valid = true; st.cam = renderCamera; st.counter = c; st.src_slot = k;
+    };
+    int have = -1;
+    for (int k = 0; k < 2; k++)
+        if (L.staged[k].valid && L.staged[k].counter == counter && same_camera(L.staged[k].cam, renderCamera)) have = k;
+    if (have < 0) { have = 0; stage(L.staged[0], cur, counter); }
+    // the batch after this one, once the run is established: traced while the caller consumes this one
+    const int next_begin = L.slot[cur].begin + L.slot[cur].count;
+    if (L.streak >= 2 && s->batch > 1 && !holds(L.slot[cur ^ 1], next_begin))
+        trace_over(cur ^ 1, next_begin, std::min(s->batch, std::max(2 * L.slot[cur].count, 2)));
+    // the next pass of the run starts its way to the host now
+    if (L.streak >= 1) {
+        const int nk = holds(L.slot[cur], counter + 1) ? cur : (holds(L.slot[cur ^ 1], counter + 1) ? (cur ^ 1) : -1);
+        if (nk >= 0) stage(L.staged[have ^ 1], nk, counter + 1);
+    }
+    hip_or_die(hipEventSynchronize(L.staged[have].done), "device-to-host copy");
+    memcpy(pixels, L.staged[have].host, pass_floats * sizeof(float));
+    L.staged[have].valid = false;
     L.last_counter = counter;
     L.last_cam = renderCamera;
     L.have_last = true;
