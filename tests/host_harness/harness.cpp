@@ -213,6 +213,38 @@ long long hh_sincos_mismatches(uint32_t first, uint32_t last, uint32_t step) {
     return bad;
 }
 
+// pt::log_f against logf and pt::pow_e_f against powf((float)E, y) for the floats with bit patterns first,
+// first + step, ... <= last (NaN results compare equal to each other).
+long long hh_log_mismatches(uint32_t first, uint32_t last, uint32_t step) {
+    long long bad = 0;
+    const long long n = ((long long)last - (long long)first) / (long long)step + 1;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long k = 0; k < n; k++) {
+        const uint32_t u = first + (uint32_t)(k * step);
+        float a;
+        memcpy(&a, &u, 4);
+        volatile float av = a;
+        const float m = pt::log_f(a), g = logf(av);
+        if (memcmp(&m, &g, 4) != 0 && !(m != m && g != g)) bad++;
+    }
+    return bad;
+}
+long long hh_pow_e_mismatches(uint32_t first, uint32_t last, uint32_t step) {
+    long long bad = 0;
+    const long long n = ((long long)last - (long long)first) / (long long)step + 1;
+    volatile float base = (float)2.7182818284590452353602874713526624977572;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long k = 0; k < n; k++) {
+        const uint32_t u = first + (uint32_t)(k * step);
+        float a;
+        memcpy(&a, &u, 4);
+        volatile float av = a;
+        const float m = pt::pow_e_f(a), g = powf(base, av);
+        if (memcmp(&m, &g, 4) != 0 && !(m != m && g != g)) bad++;
+    }
+    return bad;
+}
+
 // pt::Rng (the generator the kernels use), host build: n_draws uniforms per seed
 void hh_rng_uniforms(const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
     for (int s = 0; s < n_seeds; s++) {

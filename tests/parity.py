@@ -1,16 +1,15 @@
-"""Shared checks of the GPU parity tests: per-sample radiance of the HIP path against the oracle.
+"""Shared checks of the GPU parity tests: one pass of the HIP path against the oracle.
 
-The bar is "every sample within 1e-4 relative" (denominator floored at 1e-3).  The only samples
-allowed beyond it are those whose PATH differs: the device takes sin / cos / log / exp in double and
-rounds once, glibc's float functions differ from that by one ulp in ~0.3 % of calls, and a
-one-ulp difference at a threshold (scatter vs surface, Fresnel roulette, which primitive is
-closer) sends the path down another branch.  Both sides therefore export, for every bounce, the
-branch taken and the primitive hit; a sample whose whole sequence is identical on both sides must
-agree to 1e-4 -- no exceptions -- and the fraction of differing sequences is bounded per test at
-about twice its measured value."""
+The stated bar for radiance is 1e-4 relative per sample.  The HIP path meets a stricter one: every
+expression is evaluated in the type and order a host build of the reference gives it, without fused
+multiply-add, with IEEE division and square root, and sin / cos / log / pow restate the host C
+library's algorithms bit for bit (pt_device.h) -- so every sample of every pass must equal the oracle's
+IN EVERY BIT, and so must the record of what every bounce of every path did (branch taken, primitive
+hit).  The checks below assert exactly that; when they fail they say how far off the result is in
+the terms of the stated bar (paths that took another branch, worst relative error on identical paths)."""
 import numpy as np
 
-REL_TOL = 1e-4
+REL_TOL = 1e-4          # the stated bar; the assertion itself is equality
 
 
 def rel_err(got, ref):
@@ -22,31 +21,20 @@ def same_paths(ev_got, prim_got, ev_ref, prim_ref):
     return (ev_got == ev_ref).all(axis=1) & (prim_got == prim_ref).all(axis=1)
 
 
-def flip_bound(n):
-    """Allowed fraction of samples whose path differs.  Measured on MI355X over every scene of the tests
-    (tools/measure_flips.py, ~600 000 samples): none.  The bound is 5e-5 of the samples, and never
-    fewer than two samples."""
-    return max(2, int(np.ceil(5e-5 * n))) / float(max(1, n))
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def check_pass(got, ev_got, prim_got, ref, max_flip_fraction=None, ids=None):
+def check_pass(got, ev_got, prim_got, ref, ids=None):
     """`ref`: oracle render_pass(..., want_events=True) result; `ids`: the pixel subset it covers."""
     if ids is not None:
         got, ev_got, prim_got = got[ids], ev_got[ids], prim_got[ids]
-    if max_flip_fraction is None:
-        max_flip_fraction = flip_bound(got.shape[0])
     same = same_paths(ev_got, prim_got, ref["events"], ref["prims"])
     r = rel_err(got, ref["rgb"])
-    worst_same = float(r[same].max()) if same.any() else 0.0
-    assert worst_same <= REL_TOL, "a sample with the oracle's exact path differs by %g" % worst_same
-    flips = float((~same).mean())
-    assert flips <= max_flip_fraction, "fraction of paths that took another branch: %g" % flips
-    # pass mean over the samples with the oracle's path: 2e-4 relative
-    if same.any():
-        gm = got[same].mean(axis=0, dtype=np.float64)
-        rm = ref["rgb"][same].mean(axis=0, dtype=np.float64)
-        assert np.all(np.abs(gm - rm) <= 2e-4 * np.maximum(rm, 1e-3) + 1e-12), (gm, rm)
-    # what the flipped samples move the pass mean by is bounded by what they actually differ by
-    moved = float(np.abs(got[~same].astype(np.float64) - ref["rgb"][~same]).sum(axis=0).max()) / max(1, got.shape[0])
-    assert moved <= 2.0 * max_flip_fraction, moved
-    return {"flips": flips, "worst_same": worst_same, "beyond_tol": float((r > REL_TOL).mean()), "mean_moved": moved}
+    report = {"flips": float((~same).mean()), "worst_same": float(r[same].max()) if same.any() else 0.0,
+              "beyond_tol": float((r > REL_TOL).mean()),
+              "samples_differing_in_any_bit": int((got.view(np.uint32) != ref["rgb"].view(np.uint32)).any(axis=1).sum())}
+    assert same.all(), "paths that took another branch or hit another primitive: %s" % report
+    assert bits_equal(got, ref["rgb"]), "radiance differs from the oracle's: %s" % report
+    return report

@@ -1,7 +1,8 @@
 """CPU: the library's per-path arithmetic (pt_device.h, the code the HIP kernels call),
-compiled for the host by tests/host_harness, against the oracle.  Differences can only
-come from the transcendental policy (double-rounded sin/cos/log/exp vs glibc's float
-functions), so bounce counts agree and samples differ in the last bits only."""
+compiled for the host by tests/host_harness, against the oracle.  Every expression is
+evaluated in the type and order the reference's host build gives it, and sin / cos / log /
+pow restate the C library's algorithms bit for bit, so the two agree in every bit of every
+sample."""
 import ctypes
 import os
 
@@ -77,10 +78,9 @@ def test_default_scene_logic_parity(H, depth):
     for counter in (0, 5):
         o = O.render_pass(sph, None, cam, counter, O.params(max_depth=depth), want_hits=True)
         got, tot, fp, ft = host_render(H, None, nop, sph, cam, counter, params(depth), ids)
-        assert abs(tot - o["bounces"]) <= 4
-        assert (fp != o["hits"]["prim"]).mean() < 1e-4
-        rel = (np.abs(got - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=1)
-        assert (rel > 1e-4).mean() < 1e-3 and (rel > 0).mean() < 0.03
+        assert tot == o["bounces"]
+        assert np.array_equal(fp, o["hits"]["prim"]) and np.array_equal(ft.view(np.int32), o["hits"]["t"].view(np.int32))
+        assert np.array_equal(got.view(np.uint32), o["rgb"].view(np.uint32))
 
 
 def test_mesh_scene_logic_parity_kd_and_brute(H):
@@ -101,9 +101,9 @@ def test_mesh_scene_logic_parity_kd_and_brute(H):
         H.hh_tree_free(ctypes.c_void_p(tree))
     # kd and brute force are the same function
     assert np.array_equal(a, b) and ta == tb and np.array_equal(fpa, fpb) and np.array_equal(fta, ftb)
-    assert abs(ta - o["bounces"]) <= max(4, o["bounces"] // 500)
-    rel = (np.abs(a - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=1)
-    assert (rel > 1e-4).mean() < 4e-3
+    # every material branch incl. absorbing and scattering media: the oracle's samples bit for bit
+    assert ta == o["bounces"]
+    assert np.array_equal(a.view(np.uint32), o["rgb"].view(np.uint32))
     assert ((fpa >= 0) & (fpa < polys.size)).sum() > 50
 
 
@@ -114,3 +114,19 @@ def test_sincos_is_the_c_librarys_bit_for_bit(H):
     H.hh_sincos_mismatches.argtypes = [ctypes.c_uint32] * 3
     two_pi_bits = int(np.array([6.2831855], np.float32).view(np.uint32)[0])
     assert H.hh_sincos_mismatches(0, two_pi_bits, 1) == 0
+
+
+def test_log_and_pow_are_the_c_librarys_bit_for_bit(H):
+    """pt::log_f vs logf and pt::pow_e_f vs powf((float)E, y).  Every 5th of all 2^32 float bit patterns here (zero,
+    subnormals, negatives, infinities and NaNs included), plus whole stretches around 1, 2^-31 and the overflow /
+    underflow thresholds; the complete sweep of all 2^32 patterns (30 s) was run when the functions were written: none differ."""
+    for fn in (H.hh_log_mismatches, H.hh_pow_e_mismatches):
+        fn.restype = ctypes.c_longlong
+        fn.argtypes = [ctypes.c_uint32] * 3
+        assert fn(0, 0xFFFFFFFF, 5) == 0
+    bits = lambda x: int(np.array([x], np.float32).view(np.uint32)[0])
+    assert H.hh_log_mismatches(bits(0.99), bits(1.01), 1) == 0
+    assert H.hh_log_mismatches(bits(2.0 ** -31), bits(2.0 ** -30), 1) == 0
+    for lo, hi in ((87.0, 89.5), (-104.5, -86.5)):
+        a, b = sorted((bits(lo), bits(hi)))
+        assert H.hh_pow_e_mismatches(a, b, 1) == 0
