@@ -166,6 +166,16 @@ class Scene:
         _check(_lib.lib().gpt_debug_render_events(self._h, _ptr(cam), int(counter), _ptr(events), _ptr(prims), _ptr(out)))
         return out, events, prims
 
+    def dump_queue(self, camera, counter0, passes, depth, max_rays):
+        """gpt_debug_dump_queue: (rays[n,6], queue length) of the path queue entering `depth`."""
+        cam = _cam(camera)
+        self._ensure(cam)
+        rays = np.empty((int(max_rays), 6), dtype=np.float32)
+        n, live = ctypes.c_int(), ctypes.c_uint()
+        _check(_lib.lib().gpt_debug_dump_queue(self._h, _ptr(cam), int(counter0), int(passes), int(depth), _ptr(rays),
+                                               int(max_rays), ctypes.byref(n), ctypes.byref(live)))
+        return rays[:n.value], live.value
+
     def intersect(self, rays, use_kdtree=True):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         tri = np.empty(rays.shape[0], dtype=np.int32)

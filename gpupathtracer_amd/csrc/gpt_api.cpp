@@ -754,6 +754,54 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     return GPT_OK;
 }
 
+// The path queue as it enters depth `depth` of a batch of P passes (experiments on ray order): the first
+// `max_rays` rays (origin, direction: 6 floats each) in queue order; *out_n = how many were written,
+// *out_live = the queue's length.  Renders the batch up to that depth as a side effect (statistics and image untouched
+// beyond what the kernels add to the statistics words).
+gpt_status gpt_debug_dump_queue(gpt_scene* s, const Camera* cam, int counter0, int P, int depth, float* rays, int max_rays,
+                                int* out_n, unsigned* out_live) {
+    gpt_status st = check_render_args(s, cam);
+    if (st) return st;
+    if (!rays || !out_n || P < 1 || P > s->batch || depth < 0 || depth >= s->params.max_depth) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    GPT_ON_DEVICE(s->device);
+    const int N = s->numPixels;
+    const CamPre cp = make_cam(cam, s->params.row_stride_is_width);
+    ShadeParams sp;
+    sp.ray_bias = s->params.ray_bias;
+    sp.min_ray_weight = s->params.min_ray_weight;
+    unsigned* counts = s->d_counters;
+    unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
+    const int use_kd = (s->params.use_kdtree && s->geom.n_tris > 0) ? 1 : 0;
+    const long long total = (long long)N * P;
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
+    gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, (uint32_t)counter0,
+                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+    const int grid = (int)std::max<long long>(1, std::min<long long>(kTraceGrid, (total + kBlock - 1) / kBlock));
+    for (int d = 0; d < depth; d++) {
+        const int in = d & 1, out = in ^ 1;
+        if (s->geom.n_tris > 0)
+            gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, d, s->d_ray_o[in], s->d_ray_d[in], s->d_hit[in], counts, work,
+                           s->d_stats_scratch, s->d_spill, s->spill_stride, s->refill_below, s->leaf_min);
+        gptk_shade(s->stream, grid, &s->geom, &sp, d, (uint32_t)counter0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
+                   s->d_hit[in], s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_hit[out], s->d_pass, counts,
+                   s->d_stats_scratch, nullptr, nullptr, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned live = 0;
+    HIP_TRY(hipMemcpyAsync(&live, counts + depth, 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const size_t n = std::min<size_t>(live, (size_t)std::max(0, max_rays));
+    std::vector<float> o(n * 4), d4(n * 4);
+    const int q = depth & 1;
+    HIP_TRY(hipMemcpy(o.data(), s->d_ray_o[q], n * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d4.data(), s->d_ray_d[q], n * 16, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) { rays[6 * i + c] = o[4 * i + c]; rays[6 * i + 3 + c] = d4[4 * i + c]; }
+    *out_n = (int)n;
+    if (out_live) *out_live = live;
+    return GPT_OK;
+}
+
 // One pass as gpt_render_pass renders it, plus what every bounce of every path did.
 gpt_status gpt_debug_render_events(gpt_scene* s, const Camera* cam, int counter, unsigned char* events, int32_t* prims,
                                    float* host_pixels) {

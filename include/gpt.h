@@ -282,6 +282,11 @@ gpt_status gpt_debug_intersect(gpt_scene* scene, const float* rays, int n, int u
 gpt_status gpt_debug_render_events(gpt_scene* scene, const Camera* camera, int counter,
                                    unsigned char* events, int32_t* prims, float* host_pixels);
 
+/* The path queue entering depth `depth` of a batch of P passes starting at counter0 (experiments on ray
+ * order): its first max_rays rays (n x 6 floats, origin and direction) in queue order.  Host arrays. */
+gpt_status gpt_debug_dump_queue(gpt_scene* scene, const Camera* camera, int counter0, int P, int depth,
+                                float* rays, int max_rays, int* out_n, unsigned* out_live);
+
 /* The device's random numbers (debug/parity): out[s * n_draws + k] = k-th uniform of an engine
  * seeded with seeds[s] -- thrust::default_random_engine + uniform_real_distribution<float>(0,1)
  * as used at path_tracer_kernel.cu:139-142, 492-493.  Host arrays. */
