@@ -89,6 +89,27 @@ def test_cow_heavy_1080p_kd_vs_brute_and_oracle():
     assert np.array_equal(pr[ids][:, 0], ref["hits"]["prim"])
 
 
+def test_diamond_coil_1080p_against_oracle_subset():
+    """Config: glass diamond + subsurface (marble) coil moved into view, lens on, 1080p, depth 8 -- the long refractive and
+    in-medium tails that stress the compaction: paths, radiance and the live count of every depth on a pixel subset."""
+    w, h, depth = 1920, 1080, 8
+    cam = S.orbit_camera(w, h)
+    sph = S.default_spheres()
+    dv, dn = meshes.load_asset("diamond")
+    cv, cn = meshes.load_asset("coil")
+    polys = np.concatenate([
+        meshes.polys_from_triangles(meshes.transform(dv, 0.8, (0.2, -2.2, 2.6)), dn, S.MATERIALS["glass"]),
+        meshes.polys_from_triangles(meshes.transform(cv, 0.25, (-1.2, -2.2, 1.2)), cn, S.MATERIALS["marble"])])
+    ids = strided_ids(w, h, 11)
+    with api.Scene(sph, polys, api.render_params(max_depth=depth)) as sc:
+        for counter in (0, 3):
+            got, pr, ref = check_subset(sc, sph, polys, cam, counter, depth, ids)
+        _, ev, _ = sc.render_events(cam, 3)
+    assert (ref["events"] & 7 == 1).sum() > 50                    # scattering inside the marble happens
+    assert np.array_equal((ev[ids] > 0).sum(axis=0), ref["live"])  # live paths entering every depth
+    assert ref["live"][-1] > 0.02 * ids.size                       # and a tail still alive at the last depth
+
+
 def test_passes_per_launch_do_not_change_the_image():
     w, h = 640, 360
     cam = S.orbit_camera(w, h)

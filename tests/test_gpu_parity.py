@@ -293,6 +293,20 @@ def test_non_square_stride_modes():
             check_against_oracle(sc, sph, None, cam, 0, 6, mode)
 
 
+def test_queue_dump_is_the_camera_rays_pixel_major():
+    """gpt_debug_dump_queue at depth 0: slot i holds pass i % P of pixel i // P, and the rays are the oracle's (lens on)."""
+    w, h, P = 64, 48, 4
+    cam = S.orbit_camera(w, h)
+    with api.Scene(S.default_spheres(), None, api.render_params(max_depth=4, passes_in_flight=P)) as sc:
+        rays, live = sc.dump_queue(cam, 10, P, 0, w * h * P)
+        later, live2 = sc.dump_queue(cam, 10, P, 2, w * h * P)
+    assert live == w * h * P and rays.shape[0] == live
+    for k in range(P):
+        ref = O.camera_rays(cam, 10 + k, O.params(row_stride_is_width=1))
+        assert np.array_equal(rays[k::P].view(np.uint32), ref.view(np.uint32))
+    assert 0 < live2 < live and later.shape[0] == live2 and np.isfinite(later).all()
+
+
 def test_depth_zero_renders_black():
     """No bounce at all: the pass is black and still counted (nothing initialises the pass radiance but the library)."""
     w = h = 64
