@@ -107,6 +107,51 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
     }
 
 
+def cpu_kd_figure(spheres, polys, cam, depth, target_seconds=8.0):
+    """Context for the GPU / CPU ratio, NOT the reference's algorithm: the library's own per-path arithmetic and kd
+    traversal (pt_device.h / kd_traverse.h compiled for the host by tests/host_harness, one lane at a time, OpenMP over
+    pixels) on a strided pixel subset of the same pass.  Returns None when the harness has not been built."""
+    import ctypes
+    from gpupathtracer_amd.types import CAMERA_DTYPE, POLY_DTYPE, RENDER_PARAMS_DTYPE
+    so = os.path.join(ROOT, "tests", "host_harness", "libhh.so")
+    if polys is None or not os.path.exists(so):
+        return None
+    H = ctypes.CDLL(so)
+    H.hh_tree_build.restype = ctypes.c_void_p
+    H.hh_tree_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+    H.hh_tree_free.argtypes = [ctypes.c_void_p]
+    H.hh_render_pass.restype = ctypes.c_int64
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    w, h = int(cam["resolution"][0]), int(cam["resolution"][1])
+    verts = np.ascontiguousarray(np.concatenate([polys["p0"], polys["p1"], polys["p2"]], axis=1), dtype=np.float32)
+    rp = np.zeros(1, RENDER_PARAMS_DTYPE)
+    rp["max_depth"], rp["ray_bias"], rp["min_ray_weight"] = depth, 0.0002, 0.00001
+    rp["ground_elevation"], rp["ground_enabled"], rp["row_stride_is_width"] = -0.8, 1, 1
+    camv = np.array(cam, CAMERA_DTYPE).reshape(1)
+    polys_c = np.ascontiguousarray(polys, dtype=POLY_DTYPE)
+    tree = H.hh_tree_build(P(verts), verts.shape[0], 24, ctypes.c_float(3.0))
+    try:
+        def run(stride):
+            ys, xs = np.meshgrid(np.arange(stride // 2, h, stride), np.arange(stride // 2, w, stride), indexing="ij")
+            ids = (ys * w + xs).astype(np.int32).ravel()
+            out = np.zeros((ids.size, 3), np.float32)
+            fp, ft = np.zeros(ids.size, np.int32), np.zeros(ids.size, np.float32)
+            t0 = time.perf_counter()
+            tot = H.hh_render_pass(ctypes.c_void_p(tree), polys_c.size, P(polys_c), spheres.size, P(spheres), P(ids), ids.size, 0,
+                                   P(camv), P(rp), P(out), P(fp), P(ft))
+            return tot, time.perf_counter() - t0, ids.size
+        tot, dt, n = run(16)
+        stride = max(1, int(16 * np.sqrt(min(1.0, dt / target_seconds))))
+        if stride < 16:
+            tot, dt, n = run(stride)
+    finally:
+        H.hh_tree_free(ctypes.c_void_p(tree))
+    return {"value": tot / dt / 1e6, "unit": "Mpath-bounces/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            "kind": "port", "what": "NOT the reference's algorithm: this library's kd traversal and shading arithmetic built for the host "
+            "(tests/host_harness), OpenMP over pixels",
+            "sample": "pass counter 0, every %dth pixel in x and y (%d paths, %d path-bounces, %.1f s)" % (stride, n, tot, dt)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,6 +451,9 @@ def main(argv=None):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spheres, polys if polys is not None else None, cam, args.depth)
+            kd_fig = cpu_kd_figure(spheres, polys, cam, args.depth)
+            if kd_fig is not None:
+                out["cpu_kd_traversal"] = kd_fig
         print(json.dumps(out))
     scene.close()
     if distributed:

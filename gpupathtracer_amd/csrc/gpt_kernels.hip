@@ -668,6 +668,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGe
             }
             V3 add;
             bool has_add;
+#ifdef ABL_SHADE_PAD   // experiment: extra vector instructions per shaded path (is k_shade VALU-bound?)
+            {
+                unsigned pad_ = lane;
+#pragma unroll
+                for (int q_ = 0; q_ < ABL_SHADE_PAD; q_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_));
+            }
+#endif
             int event = 0;
             alive = shade_bounce(o, d, thr, medium, sa, ss, prim != PT_PRIM_MISS, bestT, nrm, m, matIndex,
                                  pixel, depth, seed0 + pass, sp, add, has_add, event);

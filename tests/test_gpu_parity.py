@@ -36,6 +36,22 @@ def test_device_rng_equals_thrust():
     assert (got == 1.0).sum() >= 3
 
 
+@pytest.mark.parametrize("name", ["default", "materials", "meshes"])
+def test_committed_vectors(name):
+    """The HIP path against the committed vectors of tests/golden/oracle_*.npz (no oracle call): radiance bit for bit,
+    the branch and primitive of every bounce, the live count of every depth."""
+    import os
+    import golden_scenes as G
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_%s.npz" % name))
+    sph, polys, cam, depth, counters, stride_mode = G.scene(name)
+    with api.Scene(sph, polys, api.render_params(max_depth=depth, row_stride_is_width=stride_mode)) as sc:
+        for c in counters:
+            got, ev, pr = sc.render_events(cam, c)
+            assert np.array_equal(ev, z["events_%d" % c]) and np.array_equal(pr, z["prims_%d" % c])
+            assert parity.bits_equal(got, z["rgb_%d" % c])
+            assert np.array_equal((ev > 0).sum(axis=0), z["live_%d" % c])
+
+
 def test_primary_hits_pinhole_exact():
     """No lens sampling -> no transcendental on the primary path: ids and t bit-exact."""
     w = h = 256

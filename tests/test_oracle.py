@@ -110,3 +110,17 @@ def test_tonemap_rule():
     assert out[1, 2] == 255                             # NaN
     assert out[2, 2] == 255 or out[2, 2] == 0           # pow(negative) = NaN -> 255
     assert out[2, 2] == 255
+
+
+def test_oracle_reproduces_its_committed_vectors():
+    """tests/golden/oracle_*.npz (tools/make_oracle_goldens.py): radiance, branch codes, primitives and live counts
+    of three small scenes as the oracle produced them when they were committed -- a change detector for the oracle."""
+    import golden_scenes as G
+    for name in G.NAMES:
+        z = np.load(os.path.join(HERE, "golden", "oracle_%s.npz" % name))
+        sph, polys, cam, depth, counters, stride_mode = G.scene(name)
+        for c in counters:
+            r = O.render_pass(sph, polys, cam, c, O.params(max_depth=depth, row_stride_is_width=stride_mode), want_events=True)
+            assert np.array_equal(r["rgb"].view(np.uint32), z["rgb_%d" % c].view(np.uint32)), (name, c)
+            assert np.array_equal(r["events"], z["events_%d" % c]) and np.array_equal(r["prims"], z["prims_%d" % c])
+            assert np.array_equal(r["live"], z["live_%d" % c])
