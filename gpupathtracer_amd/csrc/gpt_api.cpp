@@ -169,8 +169,8 @@ struct gpt_scene {
     // per-pixel / per-path buffers
     int numPixels = 0;
     int batch = 1;                           // passes traced together per launch
-    unsigned refill_below = 52;              // k_intersect_kd: refill a wave when fewer lanes are busy
-    unsigned leaf_min = 28;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
+    unsigned refill_below = 40;              // k_intersect_kd: refill a wave when fewer lanes are busy
+    unsigned leaf_min = 24;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};

@@ -199,16 +199,43 @@ struct DevStack {
     __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
         const int slot = (int)((unsigned)sp % KD_LDS_N);
+        // (asked of the whole wave first: a spill is rare, and a uniform branch around it costs one scalar instruction
+        // where the divergent region alone costs five)
+        if (__builtin_amdgcn_ballot_w64(sp - lo == KD_LDS_N) != 0ull) {
+        asm volatile("");
         if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
             __builtin_nontemporal_store(lds[(2 * slot + 0) * GPT_BLOCK], spill + (unsigned)(3 * lo + 0) * spill_stride);
             __builtin_nontemporal_store(lds[(2 * slot + 1) * GPT_BLOCK], spill + (unsigned)(3 * lo + 1) * spill_stride);
             __builtin_nontemporal_store((uint32_t)lds16[slot * GPT_BLOCK], spill + (unsigned)(3 * lo + 2) * spill_stride);
             lo++;
         }
+        }
         lds[(2 * slot + 0) * GPT_BLOCK] = node;
         lds[(2 * slot + 1) * GPT_BLOCK] = __float_as_uint(tmin);
         lds16[slot * GPT_BLOCK] = (uint16_t)((__float_as_uint(fmaxf(tmax - tmin, 0.0f)) + 0xffffu) >> 16);
         sp++;
+    }
+    // pop() for the lanes in `take` (each of which has an entry), executed by the whole wave: the other lanes read
+    // their top slot to no effect.  The spilled case is asked of the wave first, as in push().
+    __device__ __forceinline__ void pop_if(KdPred take, uint32_t& node, float& tmin, float& tmax) {
+        sp -= take.on() ? 1 : 0;
+        const int slot = (int)((unsigned)sp % KD_LDS_N);
+        node = lds[(2 * slot + 0) * GPT_BLOCK];
+        tmin = __uint_as_float(lds[(2 * slot + 1) * GPT_BLOCK]);
+        uint32_t len = lds16[slot * GPT_BLOCK];
+        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));
+        const KdPred spilled = take & KdPred::of(sp < lo);
+        if (spilled.bits() != 0ull) {
+            asm volatile("");
+            if (spilled.on()) {
+                node = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 0) * spill_stride);
+                tmin = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 1) * spill_stride));
+                len = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride);
+                asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));
+                lo = sp;
+            }
+        }
+        tmax = (tmin + __uint_as_float(len << 16)) * 1.000001f;
     }
     __device__ __forceinline__ bool pop(uint32_t& node, float& tmin, float& tmax) {
         if (sp == 0) return false;
@@ -340,7 +367,53 @@ __device__ __forceinline__ float bperm(unsigned byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_addr, __float_as_int(v)));
 }
 
-template <bool STATS>
+// v_min / v_max as they are: the other operand for a NaN one, and none of the canonicalising extra instructions the
+// compiler wraps around fminf / fmaxf.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// kd_root_interval without a branch (the per-axis special case of a zero direction component costs the wave three
+// divergent regions there).  The reciprocals are clamped to +-1e30 -- as good as infinite for any scene -- so that
+// 0 * inf never arises: a ray parallel to a pair of planes gets [-huge, +huge] between them and an empty interval
+// outside, which is the special case's answer.  A NaN or an infinity anywhere in the ray makes `probe` a NaN or an
+// infinity, 0 * probe a NaN, and the final comparison false: such a ray hits nothing in the reference's loop.
+__device__ __forceinline__ bool kd_root_interval_flat(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv, float& tmin,
+                                                      float& tmax) {
+    inv = v3(__builtin_amdgcn_fmed3f(kd_rcp(d.x), -1.0e30f, 1.0e30f), __builtin_amdgcn_fmed3f(kd_rcp(d.y), -1.0e30f, 1.0e30f),
+             __builtin_amdgcn_fmed3f(kd_rcp(d.z), -1.0e30f, 1.0e30f));
+    const float oc[3] = {o.x, o.y, o.z};
+    const float ic[3] = {inv.x, inv.y, inv.z};
+    float t0 = 0.0f, t1 = t_limit;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float ta = ((kd.bmin[a] - kd.sigma) - oc[a]) * ic[a], tb = ((kd.bmax[a] + kd.sigma) - oc[a]) * ic[a];
+        const float tn = vmin(ta, tb), tf = vmax(ta, tb);
+        t0 = vmax(t0, __builtin_fmaf(-PT_KD_REL_SLACK, fabsf(tn), tn));
+        t1 = vmin(t1, __builtin_fmaf(PT_KD_REL_SLACK, fabsf(tf), tf));
+    }
+    const float probe = ((o.x + o.y) + (o.z + d.x)) + (d.y + d.z);
+    tmin = t0;
+    tmax = t1;
+    return t0 <= __builtin_fmaf(probe, 0.0f, t1);
+}
+
+// FindTriangleIntersect's three results without its early return: with det == 0 the quotients are infinities or NaNs,
+// and no finite t comes out (the caller's rule "a hit must beat the best t so far" then rejects what the early return
+// rejects).  Same operations in the same order as pt::triangle_t otherwise.
+__device__ __forceinline__ void triangle_uvt(V3 a, V3 edge1, V3 edge2, V3 o, V3 d, float& bary1, float& bary2, float& t) {
+    const V3 pvec = cross(d, edge2);
+    const float det = dot(edge1, pvec);
+    const float inv_det = 1.0f / det;
+    const V3 tvec = o - a;
+    bary1 = dot(tvec, pvec) * inv_det;
+    const V3 qvec = cross(tvec, edge1);
+    bary2 = dot(d, qvec) * inv_det;
+    t = dot(edge2, qvec) * inv_det;
+}
+
+// PACKED: the leaves hold the offsets of their runs of triangle records (leaf-ordered layout); otherwise they hold
+// positions in the index list g.kd.refs.
+template <bool STATS, bool PACKED>
 __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(DevGeometry g, int depth,
                                                             const float4* __restrict__ ray_o,
                                                             const float4* __restrict__ ray_d,
@@ -356,6 +429,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     __shared__ unsigned char s_owner[GPT_BLOCK];       // per wave: 64 marks of the test phase's owner search
     const unsigned n = counts[depth];
 
+    // The scalar unit is this kernel's scarcest resource: a CU issues about one scalar instruction per cycle for its
+    // four SIMDs together (4.3 cycles per instruction and SIMD, against 2.4 for a plain vector instruction and 3.7 for a
+    // compare or a select: tools/microbench/valu_issue.hip), and eight more scalar instructions per walk iteration cost
+    // 7 - 9 % of the kernel's time, eight more vector instructions 1.5 %.  Hence the shape of everything below: which
+    // lanes hold a ray, wait at a leaf or look for their next interval is kept in wave masks (KdPred) that the code
+    // updates itself, not in per-lane bools (whose merging at every join the compiler spells out in scalar
+    // instructions); loops run on wave-uniform conditions; and decisions are made numerically where that saves masks.
     KdCursor<DevStack, STATS> cur;
     cur.st.lds = s_stack + threadIdx.x;
     cur.st.lds16 = s_stack_len + threadIdx.x;
@@ -366,25 +446,11 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     const unsigned wave_base = threadIdx.x & ~63u;
 
     uint32_t cNodes = 0, cTris = 0, cHits = 0, cBusy = 0, cRounds = 0;
-    bool have = false;          // this lane holds an unfinished traversal
-    KdPred parkedM = KdPred::none();   // lanes that stand at a leaf whose triangles wait for the test phase
+    KdPred haveM = KdPred::none();     // lanes that hold an unfinished traversal
     bool drained = false;       // wave-uniform: the work queue is exhausted
     unsigned slot = 0;          // queue slot of the ray this lane is tracing
     int prim0 = PT_PRIM_MISS;   // best among ground / spheres for that ray
     unsigned leafFirst = 0, leafCount = 0;
-    KdNode w;                   // the node a walking lane stands at
-    w.w0 = 3u; w.w1 = 0u;
-
-    // The traversal of this lane is over: a triangle that beat the ground / sphere hit
-    // replaces it in the ray's hit slot.
-#define KD_FINISH()                                                                                      \
-    do {                                                                                                 \
-        const unsigned long long key_ = __atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED);            \
-        const unsigned lo_ = (unsigned)key_;                                                             \
-        if (lo_) hit[slot] = make_float2(__uint_as_float((unsigned)(key_ >> 32)), __int_as_float((int)(lo_ - 1u))); \
-        if (STATS && (lo_ || prim0 != PT_PRIM_MISS)) cHits++;                                            \
-        have = false;                                                                                    \
-    } while (0)
 
     // The wave takes rays from the global queue KD_FETCH_CHUNK at a time (one atomic on
     // the shared counter per chunk) and hands them to idle lanes from that local range.
@@ -397,7 +463,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     for (;;) {
         // ---- refill ----
         while (!drained) {
-            const unsigned long long idle = __ballot(!have);
+            const unsigned long long idle = ~haveM.bits();
             const unsigned cnt = (unsigned)__popcll(idle);
             if (cnt == 0u || (64u - cnt) >= refill_below) break;
             if (local_next >= local_end) {
@@ -416,44 +482,58 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             }
             const unsigned avail = local_end - local_next;
             const unsigned take = cnt < avail ? cnt : avail;
-            if (!have) {
-                const unsigned r = prefix_count(idle);
-                if (r < take) {
-                    const unsigned i = local_next + r;
-                    const float4 ro = ld_stream(&ray_o[i]);
-                    const float4 rd = ld_stream(&ray_d[i]);
-                    const V3 o = v3(ro.x, ro.y, ro.z);
-                    const V3 d = v3(rd.x, rd.y, rd.z);
-                    float2 h = hit[i];          // closest among ground and spheres
-                    // (consumed here: a load still pending when the walk resumes would make every
-                    // later wait a wait for ALL outstanding loads)
-                    asm volatile("" : "+v"(h.x), "+v"(h.y));
-                    const int prim = __float_as_int(h.y);
-                    if (cur.begin(g.kd, o, d, h.x)) {
-                        have = true;
-                        slot = i;
-                        prim0 = prim;
-                        s_best[threadIdx.x] = hit_key(h.x, -1);
-                    } else if (STATS && prim != PT_PRIM_MISS) {
-                        cHits++;
-                    }
-                }
+            bool started = false;
+            if (prefix_count(idle) < take && !haveM.on()) {
+                const unsigned i = local_next + prefix_count(idle);
+                const float4 ro = ld_stream(&ray_o[i]);
+                const float4 rd = ld_stream(&ray_d[i]);
+                float2 h = hit[i];          // closest among ground and spheres
+                // (consumed here: a load still pending when the walk resumes would make every
+                // later wait a wait for ALL outstanding loads)
+                asm volatile("" : "+v"(h.x), "+v"(h.y));
+                // (every lane of the region takes the ray; one that misses the root box just is not counted into
+                // haveM and is overwritten by the next refill)
+                cur.o = v3(ro.x, ro.y, ro.z);
+                cur.d = v3(rd.x, rd.y, rd.z);
+                started = kd_root_interval_flat(g.kd, cur.o, cur.d, h.x, cur.inv, cur.tmin, cur.tmax);
+                cur.node = 0;
+                cur.st.reset();
+                slot = i;
+                prim0 = __float_as_int(h.y);
+                s_best[threadIdx.x] = hit_key(h.x, -1);
+                if (STATS && !started && prim0 != PT_PRIM_MISS) cHits++;
             }
+            haveM = haveM | KdPred::of(started);
             local_next += take;
         }
-        const unsigned nHave = (unsigned)__popcll(__ballot(have));
+        const unsigned nHave = haveM.count();
         if (nHave == 0u) {
             if (drained) break;
             continue;
         }
         // ---- walk ----
-        // (kept minimal: this loop runs once per tree level; everything that happens once per
-        // leaf -- next interval, end of traversal -- is left to the test phase)
-        const KdPred haveM = KdPred::of(have);
-        for (;;) {   // (`w` of a lane that does not walk is stale; every use is masked)
-            // the lanes' conditions are kept as wave masks (KdPred): the loop's control logic then
-            // runs on the scalar unit, and the only divergent regions are the node load and the push
-            const KdPred walkM = haveM & ~parkedM;
+        // One tree level per iteration for the lanes in walkM (everything that happens once per leaf -- next interval,
+        // end of traversal -- is left to the phases after it).  The step is KdCursor::node_step's, decided numerically:
+        // it runs with the walking lanes as the execution mask (every comparison's lane mask is then already confined
+        // to them); each child gets its interval, and a child is visited iff its interval is not empty -- two
+        // comparisons.  Which child is the near one, whether a child is an empty leaf and whether the plane lies
+        // behind the origin all enter as SIGN BITS or NaNs folded into the operands of those two comparisons instead
+        // of as masks of their own:
+        //   near child  [tmin, min(hi, tmax)], or [tmin, tmax] when lo < 0 (the crossing may lie behind the origin);
+        //   far child   [max(lo, tmin), tmax], empty when hi < 0;
+        // where [lo, hi] is the thickened plane's range of ray parameters.  With the reciprocals clamped to +-1e30 no
+        // infinities or NaNs arise, and a ray parallel to the plane gets a crossing so far out or so far back that the
+        // same rule decides it as node_step does.  Exactly on the plane both children are visited whole, in either order.
+        KdPred walkM = haveM;                                   // (no lane waits at a leaf when the phase starts)
+        const unsigned parkGoal = nHave < leaf_min ? nHave : leaf_min;
+        const unsigned walkStop = (unsigned)__builtin_amdgcn_readfirstlane((int)(nHave - parkGoal));   // leave once no more lanes than this still walk
+        do {
+#ifdef ABL_WALK_SPAD  // experiment: ABL_WALK_SPAD extra SCALAR instructions per walk iteration (is the loop bound by scalar issue?)
+            {
+#pragma unroll
+                for (int q_ = 0; q_ < ABL_WALK_SPAD; q_++) asm volatile("s_add_u32 s100, s100, 1" : : : "s100", "scc");
+            }
+#endif
 #ifdef ABL_WALK_PAD   // experiment: ABL_WALK_PAD extra vector instructions per walk iteration (is the loop VALU-bound?)
             {
                 unsigned pad_ = lane;
@@ -461,28 +541,58 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 for (int q_ = 0; q_ < ABL_WALK_PAD; q_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad_));
             }
 #endif
+            bool cont = false;
             if (walkM.on()) {
                 if (STATS) { PT_COUNT_WAVE_ITERATION(0); cNodes++; }
-                w = g.kd.nodes[cur.node];
+                const KdNode w = g.kd.nodes[cur.node];
+                const uint32_t w0 = w.w0, SIGN = 0x80000000u;
+                const unsigned axis = w0 & 3u;
+                const KdPred innerM = KdPred::of(axis != 3u);
+                const float oa = sel3((int)axis, cur.o.x, cur.o.y, cur.o.z);
+                const float ia = sel3((int)axis, cur.inv.x, cur.inv.y, cur.inv.z);
+                const float key = __uint_as_float(w.w1) - oa;       // > 0: the origin lies left of the plane
+                const uint32_t s = __float_as_uint(key) >> 31;      // 1: the right child is the near one
+                const uint32_t sx = s ^ 1u;
+                const uint32_t left = (w0 >> 2) & PT_KD_CHILD_MASK;
+                const uint32_t nearChild = left + s, farChild = left + sx;
+                const uint32_t wN = w0 << sx, wF = w0 << s;         // bit 31: the near / far child is an empty leaf
+                const float tp = key * ia;
+                const float slack = __builtin_fmaf(PT_KD_REL_SLACK, fabsf(tp), g.kd.sigma * fabsf(ia));
+                const float lo = tp - slack, hi = tp + slack;
+                // The interval ends below are compared as signed INTEGERS: for the non-negative floats involved that is
+                // the float order, and an end with the sign bit set lies below every start, +0 included (as a float, an
+                // interval [0, -0] would not be empty -- and a ray whose search ends at t = 0 would wander through half the tree).
+                // far child: the end's sign bit is set when hi < 0 or the child is an empty leaf
+                const float farTmin = vmax(lo, cur.tmin);
+                const int32_t farEnd = (int32_t)(((__float_as_uint(hi) | wF) & SIGN) | __float_as_uint(cur.tmax));
+                const KdPred farM = KdPred::of(__float_as_int(farTmin) <= farEnd);
+                // near child: hi becomes a NaN when lo < 0 (the minimum then returns tmax); the end's sign as above
+                const uint32_t behind = (uint32_t)((int32_t)__float_as_uint(lo) >> 31) & 0x7fc00000u;
+                const float nearTmax = vmin(__uint_as_float(__float_as_uint(hi) | behind), cur.tmax);
+                const int32_t nearEnd = (int32_t)((wN & SIGN) | __float_as_uint(nearTmax));
+                const KdPred nearM = KdPred::of(nearEnd >= __float_as_int(cur.tmin));
+                if ((innerM & nearM & farM).on()) cur.st.push(farChild, farTmin, cur.tmax);
+                // (a lane at a leaf computes garbage here: it takes node, tmin and tmax from its next stack entry)
+                cur.node = nearM.on() ? nearChild : farChild;
+                cur.tmin = nearM.on() ? cur.tmin : farTmin;
+                cur.tmax = nearM.on() ? nearTmax : cur.tmax;
+                // a lane stops at a leaf, or where neither child is worth a visit: nothing to test there
+                leafFirst = w0 >> 2;
+                leafCount = innerM.on() ? 0u : w.w1;                // may be 0 at a leaf, too: an empty one
+                cont = (innerM & (nearM | farM)).on();
             }
-            const KdPred innerM = walkM & KdPred::of((w.w0 & 3u) != 3u);
-            const KdPred leafM = walkM & ~innerM;
-            const KdPred deadM = cur.node_step(g.kd, w, innerM);   // only empty leaves below: same as standing in one
-            leafFirst = leafM.on() ? (w.w0 >> 2) : leafFirst;
-            leafCount = leafM.on() ? w.w1 : (deadM.on() ? 0u : leafCount);     // may be 0: an empty leaf
-            parkedM = parkedM | leafM | deadM;
-            const unsigned nPark = parkedM.count();
-            if (STATS) { if (have) cBusy++; if (lane == 0) cRounds++; }
-            if (nPark == nHave || nPark >= leaf_min) break;
-        }
-        const bool parked = parkedM.on();
+            walkM = KdPred::of(cont);
+            if (STATS) { if (haveM.on()) cBusy++; if (lane == 0) cRounds++; }
+        } while (walkM.count() > walkStop);
+        const KdPred parkedM = haveM & ~walkM;    // lanes that stand at a leaf whose triangles are tested now
         // ---- test ----
         {
-            const unsigned cnt = parked ? leafCount : 0u;
-            const bool packed = g.kd.refs == nullptr;
-            const unsigned unit = packed ? (unsigned)(sizeof(TriRec) / 8) : 1u;
+            // `first`: number of the lane's first (ray, triangle) pair; none for a lane without triangles
+            const unsigned cnt = parkedM.on() ? leafCount : 0u;
+            const unsigned unit = PACKED ? (unsigned)(sizeof(TriRec) / 8) : 1u;
             const unsigned incl = wave_inclusive_sum(cnt);
             const unsigned excl = incl - cnt;
+            const unsigned first = cnt != 0u ? excl : 0xffffffffu;
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
             for (unsigned base = 0; base < total; base += 64) {
                 if (STATS) PT_COUNT_WAVE_ITERATION(1);
@@ -492,10 +602,10 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 // maximum spreads the marks, and the run reaching in from the previous chunk belongs to
                 // the last lane that starts at or before `base`
                 s_owner[threadIdx.x] = 0;
-                if (cnt != 0u && excl >= base && excl - base < 64u) s_owner[wave_base + (excl - base)] = (unsigned char)lane;
+                if (first - base < 64u) s_owner[wave_base + (first - base)] = (unsigned char)lane;
                 __builtin_amdgcn_wave_barrier();
                 const unsigned mark = s_owner[threadIdx.x];
-                const unsigned long long before = __ballot(cnt != 0u && excl <= base);
+                const unsigned long long before = KdPred::of(first <= base).bits();
                 const unsigned carry = 63u - (unsigned)__builtin_clzll(before);
                 const unsigned L = dpp_max(wave_inclusive_max(mark), carry);
                 const unsigned la = L << 2;
@@ -512,7 +622,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 }
 #endif
                 if (p < total) {
-                    const float* rp = packed ? reinterpret_cast<const float*>(g.kd.leaf_tris) + 2 * (size_t)r0u
+                    const float* rp = PACKED ? reinterpret_cast<const float*>(g.kd.leaf_tris) + 2 * (size_t)r0u
                                              : g.kd.leaf_tris[g.kd.refs[r0u]].f;
                     // the whole record at once (left alone, the compiler fetches `a` only after the
                     // determinant test: a second memory latency in every chunk); 8-byte aligned
@@ -526,20 +636,45 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                  "+v"(r1.w), "+v"(r2.x), "+v"(r2.y));
                     const V3 a = v3(r0.x, r0.y, r0.z), e1 = v3(r0.w, r1.x, r1.y), e2 = v3(r1.z, r1.w, r2.x);
                     const int idx = __float_as_int(r2.y);
-                    float t;
                     if (STATS) cTris++;
-                    if (triangle_t(a, e1, e2, o, d, t) && t > 0.0f) atomicMin(&s_best[wave_base + L], hit_key(t, idx));
+                    // FindTriangleIntersect's acceptance (bary1 >= 0, bary2 >= 0, bary1 + bary2 <= 1) and the caller's t > 0,
+                    // in two comparisons: 1 - (bary1 + bary2) has the sign of the third condition exactly, and the
+                    // smallest of the three is >= 0 iff all are (-0 included).
+                    float b1, b2, t;
+                    triangle_uvt(a, e1, e2, o, d, b1, b2, t);
+                    const float least = vmin(vmin(b1, b2), 1.0f - (b1 + b2));
+                    if (least >= 0.0f && t > 0.0f) atomicMin(&s_best[wave_base + L], hit_key(t, idx));
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            parkedM = KdPred::none();
-            if (parked) {
-                cur.bestT = __uint_as_float((unsigned)(__atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED) >> 32));
-                if (!cur.next_interval()) KD_FINISH();
+        }
+        // ---- next interval ----
+        // The lanes that waited at a leaf take the next deferred interval that can still hold a closer (or equal) hit;
+        // a lane that has none left is done.  One stack entry per iteration for all lanes that still look, the loop
+        // itself on a wave-uniform condition.
+        {
+            const unsigned long long key = __atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED);
+            const float bestT = __uint_as_float((unsigned)(key >> 32));
+            KdPred needM = parkedM, doneM = KdPred::none();
+            while (needM.bits() != 0ull) {
+                const KdPred takeM = needM & KdPred::of(cur.st.sp != 0);
+                doneM = doneM | (needM & ~takeM);
+                uint32_t node_;
+                float tmin_, tmax_;
+                cur.st.pop_if(takeM, node_, tmin_, tmax_);
+                const KdPred acceptM = takeM & ~KdPred::of(bestT < tmin_);
+                cur.node = acceptM.on() ? node_ : cur.node;
+                cur.tmin = acceptM.on() ? tmin_ : cur.tmin;
+                cur.tmax = acceptM.on() ? vmin(tmax_, bestT) : cur.tmax;
+                needM = takeM & ~acceptM;
             }
+            // The traversal of these lanes is over: a triangle that beat the ground / sphere hit replaces it in the ray's hit slot.
+            const unsigned tri1 = (unsigned)key;     // triangle index + 1, or 0
+            if (doneM.on() && tri1 != 0u) hit[slot] = make_float2(bestT, __int_as_float((int)(tri1 - 1u)));
+            if (STATS && doneM.on() && (tri1 != 0u || prim0 != PT_PRIM_MISS)) cHits++;
+            haveM = haveM & ~doneM;
         }
     }
-#undef KD_FINISH
     if (STATS) {
         atomicAdd(&stats[GPT_STAT_KD_NODES], (unsigned long long)cNodes);
         atomicAdd(&stats[GPT_STAT_KD_TRIS], (unsigned long long)cTris);
@@ -876,12 +1011,20 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
                     unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
                     unsigned leaf_min) {
     if (use_kd) {
+#define KD_LAUNCH(STATS_)                                                                                               \
+    do {                                                                                                                \
+        if (g->kd.refs == nullptr)                                                                                      \
+            hipLaunchKernelGGL((k_intersect_kd<STATS_, true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, \
+                               hit, counts, work, stats, spill, spill_stride, refill_below, leaf_min);                   \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_intersect_kd<STATS_, false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, \
+                               hit, counts, work, stats, spill, spill_stride, refill_below, leaf_min);                  \
+    } while (0)
         if (stats_on)
-            hipLaunchKernelGGL((k_intersect_kd<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
-                               counts, work, stats, spill, spill_stride, refill_below, leaf_min);
+            KD_LAUNCH(true);
         else
-            hipLaunchKernelGGL((k_intersect_kd<false>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d, hit,
-                               counts, work, stats, spill, spill_stride, refill_below, leaf_min);
+            KD_LAUNCH(false);
+#undef KD_LAUNCH
     } else {
         if (stats_on)
             hipLaunchKernelGGL((k_intersect_brute<true>), dim3(grid), dim3(GPT_BLOCK), 0, s, *g, depth, ray_o, ray_d,

@@ -77,6 +77,7 @@ struct KdPred {
     __device__ __forceinline__ bool on() const { return __builtin_amdgcn_inverse_ballot_w64(m); }
     __device__ __forceinline__ KdPred operator~() const { KdPred p; p.m = ~m; return p; }
     __device__ __forceinline__ unsigned count() const { return (unsigned)__builtin_popcountll(m); }   // lanes set (of the active ones, for a mask made by of())
+    __device__ __forceinline__ unsigned long long bits() const { return m; }
 #else
     bool m;
     static PT_HD KdPred of(bool b) { KdPred p; p.m = b; return p; }
@@ -84,10 +85,12 @@ struct KdPred {
     PT_HD bool on() const { return m; }
     PT_HD KdPred operator~() const { KdPred p; p.m = !m; return p; }
     PT_HD unsigned count() const { return m ? 1u : 0u; }
+    PT_HD unsigned long long bits() const { return m ? ~0ull : 0ull; }
 #endif
     static PT_HD KdPred none() { return ~all(); }
     PT_HD KdPred operator&(KdPred b) const { KdPred p; p.m = m & b.m; return p; }
     PT_HD KdPred operator|(KdPred b) const { KdPred p; p.m = m | b.m; return p; }
+    PT_HD KdPred operator^(KdPred b) const { KdPred p; p.m = m ^ b.m; return p; }
 };
 
 PT_HD float bits_to_float(uint32_t u) {
