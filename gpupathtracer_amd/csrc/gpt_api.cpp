@@ -500,7 +500,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
 
         if (timing) fprintf(stderr, "gpt_scene_create: kd build %.3f s, device layout %.3f s, upload %.3f s\n", tt1 - tt0, tt2 - tt1, tnow() - tt2);
         s->spill_stride = (size_t)kTraceGrid * kBlock;
-        const size_t spill_words = 3 * (size_t)(tree.max_depth + 2) * s->spill_stride;
+        const size_t spill_words = 2 * (size_t)(tree.max_depth + 2) * s->spill_stride;
         if (spill_words >> 32) { st = fail(GPT_ERR_TOO_LARGE, "kd-tree too deep for the traversal stack"); break; }
         if (hipMalloc((void**)&s->d_spill, spill_words * 4) != hipSuccess) { st = fail(GPT_ERR_OUT_OF_MEMORY, "spill buffer"); break; }
         if (hipMalloc((void**)&s->d_counters, sizeof(unsigned) * GPT_COUNTER_WORDS) != hipSuccess ||

@@ -183,15 +183,31 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 #endif
 
 struct DevStack {
-    // An entry is 10 bytes: node, tmin, and the interval LENGTH tmax - tmin rounded UP to its upper
-    // 16 float bits.  The stored interval always contains the exact one (traversal stays
-    // conservative), and being off by < 1 % of its own length it costs next to nothing -- rounding
-    // tmax itself would misplace the end by 1 % of the DISTANCE, many leaves' worth far from the origin.
-    uint32_t* lds;          // this thread's column of words:     lds[(2*e + c) * GPT_BLOCK], c = 0 node, 1 tmin
-    uint16_t* lds16;        // this thread's column of halfwords: lds16[e * GPT_BLOCK]
-    uint32_t* spill;        // this thread's column: spill[(3*e + c) * spill_stride]
-    unsigned spill_stride;  // (3 * depth * stride fits 32 bits: checked by the host)
+    // An entry is two words.  Word 1 is tmin with its low 11 bits cleared (rounded DOWN by at most 2.4e-4 of
+    // itself: the stored interval starts a little early); the interval's LENGTH tmax - tmin, rounded UP to its upper 16
+    // float bits (15 without the sign), takes those 11 bits and the 4 bits a 28-bit node index leaves free in word 0.
+    // The stored interval always contains the exact one (traversal stays conservative); the length being off by
+    // < 1 % of itself costs next to nothing -- rounding tmax itself would misplace the end by 1 % of the DISTANCE,
+    // many leaves' worth far from the origin.  Two words instead of three mean one LDS instruction per push or pop
+    // (an LDS write costs a SIMD 18 - 27 cycles: tools/microbench/valu_issue.hip) and room for one more wave per SIMD.
+    uint32_t* lds;          // this thread's column of words: lds[(2*e + c) * GPT_BLOCK]
+    uint32_t* spill;        // this thread's column: spill[(2*e + c) * spill_stride]
+    unsigned spill_stride;  // (2 * depth * stride fits 32 bits: checked by the host)
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
+
+    static __device__ __forceinline__ void pack(uint32_t node, float tmin, float tmax, uint32_t& w0, uint32_t& w1) {
+        const uint32_t t0 = __float_as_uint(tmin) & ~0x7ffu;
+        const uint32_t len = (__float_as_uint(fmaxf(tmax - __uint_as_float(t0), 0.0f)) + 0xffffu) >> 16;
+        w0 = node | ((len >> 11) << 28);
+        w1 = t0 | (len & 0x7ffu);
+    }
+    static __device__ __forceinline__ void unpack(uint32_t w0, uint32_t w1, uint32_t& node, float& tmin, float& tmax) {
+        node = w0 & PT_KD_CHILD_MASK;
+        tmin = __uint_as_float(w1 & ~0x7ffu);
+        const uint32_t len = ((w0 >> 28) << 11) | (w1 & 0x7ffu);
+        // (the product covers the rounding of the subtraction in pack() and of this addition)
+        tmax = (tmin + __uint_as_float(len << 16)) * 1.000001f;
+    }
 
     // The spill path uses non-temporal accesses: written once, read once -- and a different
     // kind of access than the LDS path's, so the compiler cannot merge the two into generic
@@ -202,62 +218,40 @@ struct DevStack {
         // (asked of the whole wave first: a spill is rare, and a uniform branch around it costs one scalar instruction
         // where the divergent region alone costs five)
         if (__builtin_amdgcn_ballot_w64(sp - lo == KD_LDS_N) != 0ull) {
-        asm volatile("");
-        if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
-            __builtin_nontemporal_store(lds[(2 * slot + 0) * GPT_BLOCK], spill + (unsigned)(3 * lo + 0) * spill_stride);
-            __builtin_nontemporal_store(lds[(2 * slot + 1) * GPT_BLOCK], spill + (unsigned)(3 * lo + 1) * spill_stride);
-            __builtin_nontemporal_store((uint32_t)lds16[slot * GPT_BLOCK], spill + (unsigned)(3 * lo + 2) * spill_stride);
-            lo++;
+            asm volatile("");
+            if (sp - lo == KD_LDS_N) {   // the oldest LDS entry occupies the slot about to be reused
+                __builtin_nontemporal_store(lds[(2 * slot + 0) * GPT_BLOCK], spill + (unsigned)(2 * lo + 0) * spill_stride);
+                __builtin_nontemporal_store(lds[(2 * slot + 1) * GPT_BLOCK], spill + (unsigned)(2 * lo + 1) * spill_stride);
+                lo++;
+            }
         }
-        }
-        lds[(2 * slot + 0) * GPT_BLOCK] = node;
-        lds[(2 * slot + 1) * GPT_BLOCK] = __float_as_uint(tmin);
-        lds16[slot * GPT_BLOCK] = (uint16_t)((__float_as_uint(fmaxf(tmax - tmin, 0.0f)) + 0xffffu) >> 16);
+        uint32_t w0, w1;
+        pack(node, tmin, tmax, w0, w1);
+        lds[(2 * slot + 0) * GPT_BLOCK] = w0;
+        lds[(2 * slot + 1) * GPT_BLOCK] = w1;
         sp++;
     }
     // pop() for the lanes in `take` (each of which has an entry), executed by the whole wave: the other lanes read
     // their top slot to no effect.  The spilled case is asked of the wave first, as in push().
     __device__ __forceinline__ void pop_if(KdPred take, uint32_t& node, float& tmin, float& tmax) {
         sp -= take.on() ? 1 : 0;
-        const int slot = (int)((unsigned)sp % KD_LDS_N);
-        node = lds[(2 * slot + 0) * GPT_BLOCK];
-        tmin = __uint_as_float(lds[(2 * slot + 1) * GPT_BLOCK]);
-        uint32_t len = lds16[slot * GPT_BLOCK];
-        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));
-        const KdPred spilled = take & KdPred::of(sp < lo);
-        if (spilled.bits() != 0ull) {
-            asm volatile("");
-            if (spilled.on()) {
-                node = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 0) * spill_stride);
-                tmin = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 1) * spill_stride));
-                len = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride);
-                asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));
-                lo = sp;
-            }
-        }
-        tmax = (tmin + __uint_as_float(len << 16)) * 1.000001f;
-    }
-    __device__ __forceinline__ bool pop(uint32_t& node, float& tmin, float& tmax) {
-        if (sp == 0) return false;
-        sp--;
         // the LDS slot is read unconditionally (it is always a valid address) and overridden in the
         // rare spilled case; otherwise the compiler selects between the two ADDRESSES and emits
         // generic flat loads
         const int slot = (int)((unsigned)sp % KD_LDS_N);
-        node = lds[(2 * slot + 0) * GPT_BLOCK];
-        tmin = __uint_as_float(lds[(2 * slot + 1) * GPT_BLOCK]);
-        uint32_t len = lds16[slot * GPT_BLOCK];
-        asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));   // the values, not the addresses, meet below
-        if (sp < lo) {
-            node = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 0) * spill_stride);
-            tmin = __uint_as_float(__builtin_nontemporal_load(spill + (unsigned)(3 * sp + 1) * spill_stride));
-            len = __builtin_nontemporal_load(spill + (unsigned)(3 * sp + 2) * spill_stride);
-            asm volatile("" : "+v"(node), "+v"(tmin), "+v"(len));   // wait here, in the rare branch, not at a later join
-            lo = sp;
+        uint32_t w0 = lds[(2 * slot + 0) * GPT_BLOCK], w1 = lds[(2 * slot + 1) * GPT_BLOCK];
+        asm volatile("" : "+v"(w0), "+v"(w1));   // the values, not the addresses, meet below
+        const KdPred spilled = take & KdPred::of(sp < lo);
+        if (spilled.bits() != 0ull) {
+            asm volatile("");
+            if (spilled.on()) {
+                w0 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 0) * spill_stride);
+                w1 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 1) * spill_stride);
+                asm volatile("" : "+v"(w0), "+v"(w1));   // wait here, in the rare branch, not at a later join
+                lo = sp;
+            }
         }
-        // (the product covers the rounding of the subtraction above and of this addition)
-        tmax = (tmin + __uint_as_float(len << 16)) * 1.000001f;
-        return true;
+        unpack(w0, w1, node, tmin, tmax);
     }
 };
 
@@ -424,7 +418,6 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                                                             uint32_t* __restrict__ spill, size_t spill_stride,
                                                             unsigned refill_below, unsigned leaf_min) {
     __shared__ uint32_t s_stack[2 * KD_LDS_N * GPT_BLOCK];
-    __shared__ uint16_t s_stack_len[KD_LDS_N * GPT_BLOCK];
     __shared__ unsigned long long s_best[GPT_BLOCK];   // per lane: hit_key of the best hit so far
     __shared__ unsigned char s_owner[GPT_BLOCK];       // per wave: 64 marks of the test phase's owner search
     const unsigned n = counts[depth];
@@ -438,7 +431,6 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     // instructions); loops run on wave-uniform conditions; and decisions are made numerically where that saves masks.
     KdCursor<DevStack, STATS> cur;
     cur.st.lds = s_stack + threadIdx.x;
-    cur.st.lds16 = s_stack_len + threadIdx.x;
     cur.st.spill = spill + ((size_t)blockIdx.x * GPT_BLOCK + threadIdx.x);
     cur.st.spill_stride = (unsigned)spill_stride;
     cur.st.reset();

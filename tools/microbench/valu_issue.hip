@@ -1,5 +1,7 @@
 // valu_issue.hip -- issue cost of wave64 vector instructions on one SIMD (gfx950): cycles per instruction for a stream of
 // independent or dependent v_add_u32 / v_fma_f32 / v_cndmask_b32 / v_cmp_lt_f32, with W waves per SIMD competing.
+// Also LDS instructions (ds_bpermute_b32, ds_read_b32, ds_read2st64_b32, ds_read_b128, ds_write_b32, ds_write2st64_b32), in
+// groups of four with one s_waitcnt per group.
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip ; run: ./valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -8,6 +10,14 @@
 #define REP 64
 template <int KIND>
 __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, float seed) {
+    __shared__ float lds[2048];
+    lds[threadIdx.x] = seed; lds[threadIdx.x + 64] = seed; lds[threadIdx.x + 512] = seed; lds[threadIdx.x * 4 + 1024] = seed;
+    __syncthreads();
+    const unsigned ad4 = (unsigned)(size_t)lds + threadIdx.x * 4, ad16 = (unsigned)(size_t)lds + 4096 + threadIdx.x * 16;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef float vf2 __attribute__((ext_vector_type(2)));
+    vf4 q0, q1, q2, q3;
+    vf2 p0, p1, p2, p3;
     unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
     float f0 = seed + threadIdx.x, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -26,6 +36,18 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, floa
                 asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : : "vcc");
             } else if (KIND == 5) {   // scalar ALU
                 asm volatile("s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_and_b64 s[22:23], s[22:23], s[24:25]\n s_or_b64 s[26:27], s[26:27], s[24:25]" : : : "s20", "s21", "s22", "s23", "s26", "s27", "scc");
+            } else if (KIND == 7) {   // arbitrary lane permute through the LDS crossbar
+                asm volatile("ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ad4));
+            } else if (KIND == 8) {
+                asm volatile("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:256\n ds_read_b32 %2, %4 offset:512\n ds_read_b32 %3, %4 offset:768\n s_waitcnt lgkmcnt(0)" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(ad4));
+            } else if (KIND == 9) {
+                asm volatile("ds_read2st64_b32 %0, %4 offset1:2\n ds_read2st64_b32 %1, %4 offset1:2\n ds_read2st64_b32 %2, %4 offset1:2\n ds_read2st64_b32 %3, %4 offset1:2\n s_waitcnt lgkmcnt(0)" : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3) : "v"(ad4));
+            } else if (KIND == 10) {
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4\n ds_read_b128 %2, %4\n ds_read_b128 %3, %4\n s_waitcnt lgkmcnt(0)" : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) : "v"(ad16));
+            } else if (KIND == 11) {
+                asm volatile("ds_write_b32 %4, %0\n ds_write_b32 %4, %1 offset:256\n ds_write_b32 %4, %2 offset:512\n ds_write_b32 %4, %3 offset:768\n s_waitcnt lgkmcnt(0)" : : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(ad4));
+            } else if (KIND == 12) {
+                asm volatile("ds_write2st64_b32 %2, %0, %1 offset1:2\n ds_write2st64_b32 %2, %1, %0 offset1:2\n ds_write2st64_b32 %2, %0, %1 offset1:2\n ds_write2st64_b32 %2, %1, %0 offset1:2\n s_waitcnt lgkmcnt(0)" : : "v"(f0), "v"(f1), "v"(ad4));
             } else {                  // vector and scalar interleaved
                 asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, 1\n s_and_b64 s[22:23], s[22:23], s[24:25]" : "+v"(a0), "+v"(a1) : : "s20", "s22", "s23", "scc");
             }
@@ -33,6 +55,8 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, floa
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (KIND == 9) { f0 = p0.x + p1.y; f1 = p2.x + p3.y; }
+    if (KIND == 10) { f0 = q0.x + q1.y; f1 = q2.z + q3.w; }
     if (a0 + a1 + a2 + a3 == 12345u && f0 + f1 + f2 + f3 == 1.5f) out[0] = 0;
 }
 
@@ -69,6 +93,12 @@ int main() {
         run<4>("v_cmp + v_cndmask", d, w);
         run<5>("s_add / s_and / s_or", d, w);
         run<6>("v_add_u32 + scalar interleaved", d, w);
+        run<7>("ds_bpermute_b32", d, w);
+        run<8>("ds_read_b32", d, w);
+        run<9>("ds_read2st64_b32", d, w);
+        run<10>("ds_read_b128", d, w);
+        run<11>("ds_write_b32", d, w);
+        run<12>("ds_write2st64_b32", d, w);
     }
     return 0;
 }
