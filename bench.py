@@ -369,7 +369,7 @@ def main(argv=None):
         info = scene.info()
         batch = info.pop("passes_in_flight")
         if trace_share >= 0.5:
-            kernel, kernel_bytes = "k_intersect_kd<false>", kd_bytes_per_pb
+            kernel, kernel_bytes = "k_intersect_kd", kd_bytes_per_pb
             avg_launch_s = st["device_ms_trace"] / 1e3 / launches
         else:   # no (or cheap) triangle work: the shading kernel dominates; it moves everything but the tree terms
             # (the spheres' 16 bytes each are read by every path-bounce but live in the caches: left out here)
@@ -382,7 +382,7 @@ def main(argv=None):
         counter_config = {"workload": args.workload, "subdiv": args.subdiv if args.workload == "cow_heavy" else None,
                           "tris": 0 if polys is None else int(polys.size), "width": args.width, "height": args.height,
                           "depth": args.depth, "passes_per_launch": batch, "kd": info}
-        if kernel == "k_intersect_kd<false>":
+        if kernel == "k_intersect_kd":
             per_pb, traffic_source = load_traffic(args.traffic_file, counter_config)
             if per_pb is not None:
                 traffic = per_pb * pb_per_launch

@@ -21,7 +21,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
 summary = os.path.join(out, tag + "_pmc_summary.json")
 parse_prof.main(src, summary)
 d = json.load(open(summary))
-key = [k for k in d["counters"] if "k_intersect_kd<false>" in k][0]
+key = [k for k in d["counters"] if "k_intersect_kd<false" in k][0]
 c = d["counters"][key]
 n = c["_dispatches"]["pmc_rdreq"]
 read_bytes = 32 * c["TCC_EA0_RDREQ_32B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c["TCC_EA0_RDREQ_128B_sum"]
@@ -77,7 +77,7 @@ def per_kernel(name):
     }
 
 
-d["derived_per_kernel"] = {n: per_kernel(n) for n in ("k_intersect_kd<false>", "k_shade", "k_camera", "k_finish")}
+d["derived_per_kernel"] = {n: per_kernel(n) for n in ("k_intersect_kd<false", "k_shade", "k_camera", "k_finish")}
 json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
 json.dump({
     "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
