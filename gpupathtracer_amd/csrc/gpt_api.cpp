@@ -1026,7 +1026,7 @@ gpt_status gpt_accum_allreduce(gpt_scene* const* scenes, int n) {
 #define GPT_NOALLOC_OFF_STATS (GPT_NOALLOC_OFF_COUNTERS + GPT_NOALLOC_COUNTER_BYTES)
 #define GPT_NOALLOC_STAT_BYTES ((8ull * GPT_STAT_WORDS + 255ull) / 256ull * 256ull)
 #define GPT_NOALLOC_OFF_SPILL (GPT_NOALLOC_OFF_STATS + GPT_NOALLOC_STAT_BYTES)
-#define GPT_NOALLOC_SPILL_BYTES (4ull * 3ull * GPT_NOALLOC_SPILL_LEVELS * GPT_NOALLOC_THREADS)
+#define GPT_NOALLOC_SPILL_BYTES (4ull * 2ull * GPT_NOALLOC_SPILL_LEVELS * GPT_NOALLOC_THREADS)   /* two words per stack entry */
 #define GPT_NOALLOC_BYTES (GPT_NOALLOC_OFF_SPILL + GPT_NOALLOC_SPILL_BYTES)
 
 static __device__ __align__(256) unsigned char scratch[GPT_NOALLOC_BYTES];

@@ -121,7 +121,11 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
     // vector loads whose wait also drains every store the lane has in flight.
     typedef float cf4 __attribute__((ext_vector_type(4)));
     const __attribute__((address_space(4))) cf4* sph = (const __attribute__((address_space(4))) cf4*)(unsigned long long)g.spheres;
+#ifdef ABL_NO_SPHERES   // experiment (wrong pictures): what do the sphere tests of new rays cost?
+    const int n = 0;
+#else
     const int n = g.n_spheres;
+#endif
     for (int s = 0; s < n; s++) {
         const cf4 sp = sph[s];
         if (sphere_closer(v3(sp.x, sp.y, sp.z), sp.w /* radius^2 */, o, d, bestT)) prim = PT_PRIM_SPHERE | s;

@@ -298,7 +298,7 @@ gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds
  * entries each) are DEVICE pointers on the scene's GPU; results are those of
  * gpt_debug_intersect, bit for bit.  The call allocates and frees nothing: its ray
  * queue, hit slots, counters and traversal-stack spill area live in one
- * file-scope device array of 13.2 MiB that every GPU the library runs on holds
+ * file-scope device array of 8.6 MiB that every GPU the library runs on holds
  * until the process ends.  Limits (GPT_ERR_TOO_LARGE beyond them): at most
  * GPT_NOALLOC_MAX_RAYS rays per call, kd-tree depth at most 62.  All calls on one
  * GPU share that array: calls that overlap on one GPU race (serialise them);
