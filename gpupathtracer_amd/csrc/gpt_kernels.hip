@@ -375,8 +375,8 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 // 0 * inf never arises: a ray parallel to a pair of planes gets [-huge, +huge] between them and an empty interval
 // outside, which is the special case's answer.  A NaN or an infinity anywhere in the ray makes `probe` a NaN or an
 // infinity, 0 * probe a NaN, and the final comparison false: such a ray hits nothing in the reference's loop.
-__device__ __forceinline__ bool kd_root_interval_flat(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv, float& tmin,
-                                                      float& tmax) {
+__device__ __forceinline__ bool kd_root_interval_flat(const KdView& kd, float sigma, V3 o, V3 d, float t_limit, V3& inv,
+                                                      float& tmin, float& tmax) {
     inv = v3(__builtin_amdgcn_fmed3f(kd_rcp(d.x), -1.0e30f, 1.0e30f), __builtin_amdgcn_fmed3f(kd_rcp(d.y), -1.0e30f, 1.0e30f),
              __builtin_amdgcn_fmed3f(kd_rcp(d.z), -1.0e30f, 1.0e30f));
     const float oc[3] = {o.x, o.y, o.z};
@@ -384,7 +384,7 @@ __device__ __forceinline__ bool kd_root_interval_flat(const KdView& kd, V3 o, V3
     float t0 = 0.0f, t1 = t_limit;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float ta = ((kd.bmin[a] - kd.sigma) - oc[a]) * ic[a], tb = ((kd.bmax[a] + kd.sigma) - oc[a]) * ic[a];
+        const float ta = ((kd.bmin[a] - sigma) - oc[a]) * ic[a], tb = ((kd.bmax[a] + sigma) - oc[a]) * ic[a];
         const float tn = vmin(ta, tb), tf = vmax(ta, tb);
         t0 = vmax(t0, __builtin_fmaf(-PT_KD_REL_SLACK, fabsf(tn), tn));
         t1 = vmin(t1, __builtin_fmaf(PT_KD_REL_SLACK, fabsf(tf), tf));
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 // haveM and is overwritten by the next refill)
                 cur.o = v3(ro.x, ro.y, ro.z);
                 cur.d = v3(rd.x, rd.y, rd.z);
-                started = kd_root_interval_flat(g.kd, cur.o, cur.d, h.x, cur.inv, cur.tmin, cur.tmax);
+                cur.sigma = kd_ray_sigma(g.kd, cur.o);
+                started = kd_root_interval_flat(g.kd, cur.sigma, cur.o, cur.d, h.x, cur.inv, cur.tmin, cur.tmax);
                 cur.node = 0;
                 cur.st.reset();
                 slot = i;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const uint32_t nearChild = left + s, farChild = left + sx;
                 const uint32_t wN = w0 << sx, wF = w0 << s;         // bit 31: the near / far child is an empty leaf
                 const float tp = key * ia;
-                const float slack = __builtin_fmaf(PT_KD_REL_SLACK, fabsf(tp), g.kd.sigma * fabsf(ia));
+                const float slack = __builtin_fmaf(PT_KD_REL_SLACK, fabsf(tp), cur.sigma * fabsf(ia));
                 const float lo = tp - slack, hi = tp + slack;
                 // The interval ends below are compared as signed INTEGERS: for the non-negative floats involved that is
                 // the float order, and an end with the sign bit set lies below every start, +0 included (as a float, an

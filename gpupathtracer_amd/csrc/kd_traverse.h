@@ -37,7 +37,9 @@ struct KdView {
     float sigma;       // spatial slack: 2e-5 * largest extent of the root box
 };
 
+#ifndef PT_KD_REL_SLACK
 #define PT_KD_REL_SLACK 4e-6f
+#endif
 #define PT_KD_CHILD_MASK 0x0fffffffu   // child index field of an inner node's w0 (above the 2 axis bits)
 
 // Sets bits 30 / 31 in the w0 of every inner node whose left / right child is an empty leaf
@@ -132,7 +134,21 @@ PT_HD int load_tri(const TriRec* tris, size_t slot, V3& a, V3& e1, V3& e2) {
 // The part of the ray within [0, t_limit] that lies inside the root box padded by the slack; false:
 // none (or a NaN component: such a ray hits nothing in the reference's loop -- every comparison of its
 // triangle test fails -- and must not wander through the tree either).  `inv` receives 1 / d.
-PT_HD bool kd_root_interval(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv, float& tmin, float& tmax) {
+// The plane thickness a ray is traversed with: the tree's sigma (2e-5 of the scene's extent) plus 2e-6 of the ray origin's
+// distance from the middle of the root box.  The triangle test forms `origin - vertex` first; far from the mesh that
+// difference is rounded to half an ulp of the DISTANCE, which moves the test's idea of where the ray passes by up to
+// ~5e-7 of it -- for an origin 10 000 scene extents away, more than sigma.  The traversal must visit every leaf the
+// brute-force loop could report a hit in, rounding artefacts included, so its planes thicken with the distance.
+#ifndef PT_KD_DISTANCE_SLACK
+#define PT_KD_DISTANCE_SLACK 2e-6f
+#endif
+PT_HD float kd_ray_sigma(const KdView& kd, V3 o) {
+    const float dx = fabsf(o.x - 0.5f * (kd.bmin[0] + kd.bmax[0])), dy = fabsf(o.y - 0.5f * (kd.bmin[1] + kd.bmax[1])),
+                dz = fabsf(o.z - 0.5f * (kd.bmin[2] + kd.bmax[2]));
+    return kd.sigma + PT_KD_DISTANCE_SLACK * fmaxf(dx, fmaxf(dy, dz));
+}
+
+PT_HD bool kd_root_interval(const KdView& kd, float sigma, V3 o, V3 d, float t_limit, V3& inv, float& tmin, float& tmax) {
     if (!(o.x == o.x && o.y == o.y && o.z == o.z && d.x == d.x && d.y == d.y && d.z == d.z)) return false;
     tmin = 0.0f;
     tmax = t_limit;
@@ -144,7 +160,7 @@ PT_HD bool kd_root_interval(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv
 #pragma unroll
 #endif
     for (int a = 0; a < 3; a++) {
-        float lo = kd.bmin[a] - kd.sigma, hi = kd.bmax[a] + kd.sigma;
+        float lo = kd.bmin[a] - sigma, hi = kd.bmax[a] + sigma;
         if (dc[a] != 0.0f) {
             float iv = ic[a];
             float ta = (lo - oc[a]) * iv, tb = (hi - oc[a]) * iv;
@@ -172,6 +188,7 @@ PT_HD bool kd_root_interval(const KdView& kd, V3 o, V3 d, float t_limit, V3& inv
 template <class Stack, bool STATS>
 struct KdCursor {
     V3 o, d, inv;
+    float sigma;                 // this ray's plane thickness (kd_ray_sigma)
     float tmin, tmax, bestT;
     int bestTri;
     uint32_t node;
@@ -182,7 +199,8 @@ struct KdCursor {
         o = o_; d = d_;
         bestT = t_limit;
         bestTri = -1;
-        if (!kd_root_interval(kd, o, d, t_limit, inv, tmin, tmax)) return false;
+        sigma = kd_ray_sigma(kd, o);
+        if (!kd_root_interval(kd, sigma, o, d, t_limit, inv, tmin, tmax)) return false;
         node = 0;
         st.reset();
         return true;
@@ -228,9 +246,9 @@ struct KdCursor {
         // (1 / d is infinite for d = 0; a finite reciprocal beyond 3e38 belongs to a ray that moves
         // less than 1e-29 along the axis over any interval -- parallel as well.  One comparison.)
         const KdPred parallel = KdPred::of(fabsf(ia) > 3.0e38f);
-        const KdPred inSlab = KdPred::of(fabsf(oa - split) <= kd.sigma);
+        const KdPred inSlab = KdPred::of(fabsf(oa - split) <= sigma);
         const float tp = (split - oa) * ia;
-        const float s = kd.sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
+        const float s = sigma * fabsf(ia) + PT_KD_REL_SLACK * fabsf(tp);
         const float lo = tp - s, hi = tp + s;
         const KdPred crossing = ~parallel & ~(KdPred::of(lo > tmax) | KdPred::of(hi < 0.0f));   // the plane is met within the interval
         const KdPred behind = KdPred::of(lo < 0.0f);

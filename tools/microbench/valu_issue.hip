@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, floa
     typedef float vf4 __attribute__((ext_vector_type(4)));
     typedef float vf2 __attribute__((ext_vector_type(2)));
     vf4 q0, q1, q2, q3;
-    vf2 p0, p1, p2, p3;
+    vf2 p0 = {seed, seed}, p1 = {seed, 1.0f}, p2 = {1.0f, seed}, p3 = {seed, seed};
     unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
     float f0 = seed + threadIdx.x, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, floa
                 asm volatile("ds_write_b32 %4, %0\n ds_write_b32 %4, %1 offset:256\n ds_write_b32 %4, %2 offset:512\n ds_write_b32 %4, %3 offset:768\n s_waitcnt lgkmcnt(0)" : : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(ad4));
             } else if (KIND == 12) {
                 asm volatile("ds_write2st64_b32 %2, %0, %1 offset1:2\n ds_write2st64_b32 %2, %1, %0 offset1:2\n ds_write2st64_b32 %2, %0, %1 offset1:2\n ds_write2st64_b32 %2, %1, %0 offset1:2\n s_waitcnt lgkmcnt(0)" : : "v"(f0), "v"(f1), "v"(ad4));
+            } else if (KIND == 13) {  // packed fp32: two multiplications / additions per lane and instruction
+                asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_add_f32 %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            } else if (KIND == 14) {  // packed fp32 with a scalar-register pair and a broadcast low half as sources
+                asm volatile("v_pk_mul_f32 %0, %0, s[20:21]\n v_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %2, s[20:21]\n v_pk_add_f32 %3, %3, %0 op_sel_hi:[1,0]" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
             } else {                  // vector and scalar interleaved
                 asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, 1\n s_and_b64 s[22:23], s[22:23], s[24:25]" : "+v"(a0), "+v"(a1) : : "s20", "s22", "s23", "scc");
             }
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, int iters, floa
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-    if (KIND == 9) { f0 = p0.x + p1.y; f1 = p2.x + p3.y; }
+    if (KIND == 9 || KIND == 13 || KIND == 14) { f0 = p0.x + p1.y; f1 = p2.x + p3.y; }
     if (KIND == 10) { f0 = q0.x + q1.y; f1 = q2.z + q3.w; }
     if (a0 + a1 + a2 + a3 == 12345u && f0 + f1 + f2 + f3 == 1.5f) out[0] = 0;
 }
@@ -99,6 +103,8 @@ int main() {
         run<10>("ds_read_b128", d, w);
         run<11>("ds_write_b32", d, w);
         run<12>("ds_write2st64_b32", d, w);
+        run<13>("v_pk_mul_f32 / v_pk_add_f32", d, w);
+        run<14>("v_pk with sgpr pair / op_sel_hi", d, w);
     }
     return 0;
 }
