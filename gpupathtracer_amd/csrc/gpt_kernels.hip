@@ -703,6 +703,8 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
 #define SHADE_BLOCK 256   // threads per workgroup of k_shade
 #endif
 #define SHADE_STAGE (SHADE_FLUSH + SHADE_BLOCK)
+// (one flush per tile: what a tile can add -- SHADE_BLOCK survivors -- must not exceed a flush, or the staging area overflows)
+static_assert(SHADE_FLUSH >= SHADE_BLOCK && SHADE_FLUSH % SHADE_BLOCK == 0, "SHADE_FLUSH must be a multiple of SHADE_BLOCK");
 
 // FIRST: the launch that shades the primary rays.  k_camera stores no throughput for them: it is (1, 1, 1),
 // and slot i of the still uncompacted queue belongs to pass i - pixel * numPasses.
