@@ -2,6 +2,11 @@
 // independent or dependent v_add_u32 / v_fma_f32 / v_cndmask_b32 / v_cmp_lt_f32, with W waves per SIMD competing.
 // Also LDS instructions (ds_bpermute_b32, ds_read_b32, ds_read2st64_b32, ds_read_b128, ds_write_b32, ds_write2st64_b32), in
 // groups of four with one s_waitcnt per group.
+// And packed fp32 (v_pk_mul_f32 / v_pk_add_f32, also with a scalar-register pair and a broadcast low half as sources).
+// Measured on MI355X at 8 waves per SIMD, cycles of a SIMD's time per wave64 instruction (2.4 GHz assumed): plain vector
+// 2.4 - 2.7, compare + select 3.7, scalar 4.3 (the CU's scalar unit serves its four SIMDs), vector and scalar interleaved
+// 2.5 (they overlap), packed fp32 5.0 (no gain over two plain instructions), ds_read_b32 10, ds_read2st64_b32 / ds_read_b128
+// 18.5, ds_write_b32 18.5, ds_write2st64_b32 27.5, ds_bpermute_b32 26.
 // Build: hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip ; run: ./valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
