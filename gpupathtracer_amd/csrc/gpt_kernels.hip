@@ -625,8 +625,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                     // determinant test: a second memory latency in every chunk); 8-byte aligned
                     typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
                     typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+#ifdef KD_TRI_NT   // experiment: triangle records fetched with the non-temporal hint (they are 20x the nodes and reused less)
+                    const f4a8 q0 = __builtin_nontemporal_load(reinterpret_cast<const f4a8*>(rp)), q1 = __builtin_nontemporal_load(reinterpret_cast<const f4a8*>(rp + 4));
+                    const f2a8 q2 = __builtin_nontemporal_load(reinterpret_cast<const f2a8*>(rp + 8));
+#else
                     const f4a8 q0 = *reinterpret_cast<const f4a8*>(rp), q1 = *reinterpret_cast<const f4a8*>(rp + 4);
                     const f2a8 q2 = *reinterpret_cast<const f2a8*>(rp + 8);
+#endif
                     float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w);
                     float4 r2 = make_float4(q2.x, q2.y, 0.0f, 0.0f);
                     asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z),
