@@ -305,7 +305,7 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_intersect_brute(DevGeometry g, in
 // k_intersect_kd: closest hit with kd-tree traversal.
 //
 // Rays differ widely in traversal length (most miss the mesh's box at once, a
-// few walk hundreds of nodes), and the kernel is bound by VALU issue: every
+// few walk hundreds of nodes), and the kernel is bound by instruction issue: every
 // wave instruction costs the same whether 64 lanes or 5 take part.  So a wave
 // neither owns a fixed set of 64 rays nor lets each lane loop over its own
 // leaf.  Each lane holds a resumable traversal cursor; the wave alternates
