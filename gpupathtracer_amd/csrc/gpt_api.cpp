@@ -29,7 +29,7 @@ using pt::TriRec;
 extern "C" {
 void gptk_camera(hipStream_t s, int grid, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses,
                  uint32_t seed0, float4* ray_o, float4* ray_d, float4* thr, float2* hit, float4* pass_rgb,
-                 unsigned* counts);
+                 unsigned* counts, uint32_t* masks);
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
                     unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
@@ -176,6 +176,7 @@ struct gpt_scene {
     float4* d_thr[2] = {nullptr, nullptr};
     float2* d_hit[2] = {nullptr, nullptr};   // per queue: closest hit of each ray (t, primitive)
     float4* d_pass = nullptr;
+    uint32_t* d_sphere_mask = nullptr;   // per pixel: the spheres its primary rays can reach (k_camera_masks)
     float4* d_image = nullptr;
     float* d_pass3 = nullptr;
     unsigned* d_counters = nullptr;          // GPT_COUNTER_WORDS
@@ -210,7 +211,9 @@ gpt_status free_pixel_buffers(gpt_scene* s) {
     if (s->d_pass) HIP_TRY(hipFree(s->d_pass));
     if (s->d_image) HIP_TRY(hipFree(s->d_image));
     if (s->d_pass3) HIP_TRY(hipFree(s->d_pass3));
+    if (s->d_sphere_mask) HIP_TRY(hipFree(s->d_sphere_mask));
     s->d_hit[0] = s->d_hit[1] = nullptr; s->d_pass = nullptr; s->d_image = nullptr; s->d_pass3 = nullptr;
+    s->d_sphere_mask = nullptr;
     s->numPixels = 0;
     return GPT_OK;
 }
@@ -276,7 +279,7 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
     gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, seed0,
-                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts, s->d_sphere_mask);
     // (the first shade launch initialises the pass radiance slots; without any bounce nobody does)
     if (s->params.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_pass, 0, (size_t)total * sizeof(float4), s->stream));
     // every ray arrives with its closest ground / sphere hit: without triangles there is nothing to intersect
@@ -584,6 +587,7 @@ gpt_status gpt_scene_reset(gpt_scene* s, int numPixels) {
         HIP_TRY(hipMalloc((void**)&s->d_pass, n * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&s->d_image, (size_t)numPixels * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&s->d_pass3, (size_t)numPixels * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s->d_sphere_mask, (size_t)numPixels * sizeof(uint32_t)));
         s->numPixels = numPixels;
         s->batch = batch;
     }
@@ -730,7 +734,7 @@ gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, 
     unsigned* work = s->d_counters + GPT_MAX_DEPTH_SLOTS;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
     gptk_camera(s->stream, pixel_grid(N), &s->geom, &cp, N, 1, (uint32_t)counter, s->d_ray_o[0], s->d_ray_d[0],
-                s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+                s->d_thr[0], s->d_hit[0], s->d_pass, counts, s->d_sphere_mask);
     const int grid = std::max(1, std::min(kTraceGrid, (N + kBlock - 1) / kBlock));
     // statistics are not touched by this query: the kernel gets the scene's scratch copy of the stats words
     unsigned long long* scratch_stats = s->d_stats_scratch;
@@ -775,7 +779,7 @@ gpt_status gpt_debug_dump_queue(gpt_scene* s, const Camera* cam, int counter0, i
     const long long total = (long long)N * P;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
     gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, (uint32_t)counter0,
-                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts);
+                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts, s->d_sphere_mask);
     const int grid = (int)std::max<long long>(1, std::min<long long>(kTraceGrid, (total + kBlock - 1) / kBlock));
     for (int d = 0; d < depth; d++) {
         const int in = d & 1, out = in ^ 1;

@@ -101,6 +101,13 @@ __device__ __forceinline__ Mat load_material(const float4* __restrict__ mats, in
     return m;
 }
 
+// Inclusive wave64 scans in registers (DPP row shifts, then the two row broadcasts; every lane
+// of the wave must be active).  Lanes without a source take the identity 0.
+#define GPT_DPP_STEP(op, v, ctrl, row_mask) \
+    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, row_mask, 0xf, false))
+__device__ __forceinline__ unsigned dpp_add(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned dpp_max(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned dpp_or(unsigned a, unsigned b) { return a | b; }
 // ---------------------------------------------------------------------------
 // Closest hit among the ground plane and the spheres (traceRayKernel :509-533).
 // The kernel that CREATES a ray (k_camera, k_shade) runs this for it, with all
@@ -142,6 +149,72 @@ __device__ __forceinline__ void analytic_hits(const DevGeometry& g, V3 o, V3 d, 
 // rays that start from neighbouring surface points -- which keeps a wave's kd
 // traversal in the same nodes and leaves.
 // ---------------------------------------------------------------------------
+// analytic_hits with the spheres named by `mask` only (bit s = sphere s; at most 32 spheres), in ascending order like the
+// full loop.  `mask` must be wave-uniform: the loop then runs on the scalar unit and the sphere table is read by scalar loads.
+__device__ __forceinline__ void analytic_hits_masked(const DevGeometry& g, V3 o, V3 d, uint32_t mask, float& bestT_out,
+                                                     int& prim_out) {
+    float bestT = PT_T_START;
+    int prim = PT_PRIM_MISS;
+    if (g.ground_enabled) {
+        const float t = ground_t(g.ground_elevation, o, d);
+        if (t > 0) { bestT = t; prim = PT_PRIM_GROUND; }
+    }
+    typedef float cf4 __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(4))) cf4* sph = (const __attribute__((address_space(4))) cf4*)(unsigned long long)g.spheres;
+    for (uint32_t m = mask; m != 0u; m &= m - 1u) {
+        const int s = __builtin_ctz(m);
+        const cf4 sp = sph[s];
+        if (sphere_closer(v3(sp.x, sp.y, sp.z), sp.w /* radius^2 */, o, d, bestT)) prim = PT_PRIM_SPHERE | s;
+    }
+    bestT_out = bestT;
+    prim_out = prim;
+}
+
+// ---------------------------------------------------------------------------
+// k_camera_masks: for every pixel, the spheres a primary ray of that pixel can possibly hit (bit s of masks[pixel]),
+// once per batch -- the camera is the same for all its passes -- so that k_camera tests one or two spheres per ray
+// instead of all of them.  Conservative by construction; a sphere left out is one no ray of the pixel reaches, so
+// the rays' hits are those of the full loop.
+// The rays of a pixel: origin within `aperture` of the camera position, through a point of the focal plane within
+// rho = focal * (|horizontal| / (resx - 1) + |vertical| / (resy - 1)) of the pixel centre's (the jitter is half a pixel
+// either way).  At parameter s along the central ray (0: camera, 1: focal plane) such a ray is at most
+// |1 - s| * aperture + s * rho away from it.  A ray that meets the sphere (centre C, radius R) does so at a point whose
+// central-ray counterpart is within C's distance + R + that deviation of the camera, which bounds s; the sphere is kept
+// when its centre is no further from the central LINE than R + the deviation at that s (1 % and a little added).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(GPT_BLOCK) void k_camera_masks(DevGeometry g, CamPre cam, int numPixels,
+                                                            uint32_t* __restrict__ masks) {
+    const int pixel = (int)(blockIdx.x * GPT_BLOCK + threadIdx.x);
+    if (pixel >= numPixels) return;
+    const int y = (int)(pixel / cam.stride);
+    const int x = (int)(pixel - (y * cam.stride));
+    const float sx = (float)x / cam.resx_m1, sy = (float)y / cam.resy_m1;
+    const V3 onePlane = cam.middle + (((2 * sx) - 1) * cam.horizontal) + (((2 * sy) - 1) * cam.vertical);
+    const V3 dirc = onePlane - cam.position;
+    const float len1 = length(dirc);
+    const float Lc = cam.focal * len1;                      // camera -> the pixel centre's point of the focal plane
+    const float rho = 1.01f * fabsf(cam.focal) * (length(cam.horizontal) / cam.resx_m1 + length(cam.vertical) / cam.resy_m1);
+    const float a = cam.lens ? 1.01f * cam.aperture : 0.0f;
+    const float denom = Lc - rho - a;
+    uint32_t mask = 0;
+    const int n = g.n_spheres < 32 ? g.n_spheres : 32;
+    for (int s = 0; s < n; s++) {
+        const float4 sp = g.spheres[s];
+        const V3 w = v3(sp.x, sp.y, sp.z) - cam.position;
+        const float R = sqrtf(sp.w), dist = length(w);
+        bool keep = true;
+        if (denom > 0.05f * Lc && len1 > 0.0f) {
+            const float smax = (dist + R + a) / denom;
+            const float reach = 1.01f * (R + a + smax * (rho + a)) + 1e-4f * (dist + R);
+            const float proj = dot(w, dirc) / len1;
+            const float perp2 = dist * dist - proj * proj;
+            keep = !(perp2 > reach * reach);                // (a NaN keeps the sphere)
+        }
+        if (keep) mask |= 1u << s;
+    }
+    masks[pixel] = mask;
+}
+
 __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam, int numPixels, int numPasses,
                                                       uint32_t seed0,
                                                       float4* __restrict__ ray_o,
@@ -149,23 +222,42 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
                                                       float4* __restrict__ thr,
                                                       float2* __restrict__ hit,
                                                       float4* __restrict__ pass_rgb,
-                                                      unsigned* __restrict__ counts) {
+                                                      unsigned* __restrict__ counts,
+                                                      const uint32_t* __restrict__ masks) {
     const unsigned total = (unsigned)numPixels * (unsigned)numPasses;
     const unsigned stride = gridDim.x * GPT_BLOCK;
-    for (unsigned i = blockIdx.x * GPT_BLOCK + threadIdx.x; i < total; i += stride) {
-        const int pixel = (int)(i / (unsigned)numPasses);
-        const unsigned pass = i - (unsigned)pixel * (unsigned)numPasses;
+    // (the loop is block-uniform: the union of a wave's sphere masks is formed with all its lanes)
+    for (unsigned base = blockIdx.x * GPT_BLOCK; base < total; base += stride) {
+        const unsigned i = base + threadIdx.x;
+        const bool in = i < total;
+        const int pixel = (int)((in ? i : total - 1u) / (unsigned)numPasses);
+        const unsigned pass = (in ? i : total - 1u) - (unsigned)pixel * (unsigned)numPasses;
         V3 o, d;
         camera_ray(cam, pixel, seed0 + pass, o, d);
-        st_stream(&ray_o[i], make_float4(o.x, o.y, o.z, __int_as_float(pixel)));
-        st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
-        // (no throughput is stored for a primary ray, and its pass radiance slot is not cleared here:
-        // k_shade<true> handles every slot of the uncompacted queue exactly once and starts the slot with
-        // what the first bounce adds, or zero)
         float bestT;
         int prim;
-        analytic_hits(g, o, d, bestT, prim);
-        st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
+        if (masks) {
+            // the spheres any ray of this wave can reach: one or two pixels' worth with many passes per launch,
+            // 64 neighbouring pixels' with one
+            unsigned m = in ? masks[pixel] : 0u;
+            GPT_DPP_STEP(dpp_or, m, 0x111, 0xf);
+            GPT_DPP_STEP(dpp_or, m, 0x112, 0xf);
+            GPT_DPP_STEP(dpp_or, m, 0x114, 0xf);
+            GPT_DPP_STEP(dpp_or, m, 0x118, 0xf);
+            GPT_DPP_STEP(dpp_or, m, 0x142, 0xa);
+            GPT_DPP_STEP(dpp_or, m, 0x143, 0xc);
+            analytic_hits_masked(g, o, d, (uint32_t)__builtin_amdgcn_readlane((int)m, 63), bestT, prim);
+        } else {
+            analytic_hits(g, o, d, bestT, prim);
+        }
+        if (in) {
+            st_stream(&ray_o[i], make_float4(o.x, o.y, o.z, __int_as_float(pixel)));
+            st_stream(&ray_d[i], make_float4(d.x, d.y, d.z, __int_as_float(-1)));   // medium: air
+            // (no throughput is stored for a primary ray, and its pass radiance slot is not cleared here:
+            // k_shade<true> handles every slot of the uncompacted queue exactly once and starts the slot with
+            // what the first bounce adds, or zero)
+            st_stream(&hit[i], make_float2(bestT, __int_as_float(prim)));
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = total;
 }
@@ -333,12 +425,6 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int tri) {
     return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)(tri + 1);
 }
 
-// Inclusive wave64 scans in registers (DPP row shifts, then the two row broadcasts; every lane
-// of the wave must be active).  Lanes without a source take the identity 0.
-#define GPT_DPP_STEP(op, v, ctrl, row_mask) \
-    v = op(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, row_mask, 0xf, false))
-__device__ __forceinline__ unsigned dpp_add(unsigned a, unsigned b) { return a + b; }
-__device__ __forceinline__ unsigned dpp_max(unsigned a, unsigned b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
     GPT_DPP_STEP(dpp_add, v, 0x111, 0xf);   // row_shr:1
     GPT_DPP_STEP(dpp_add, v, 0x112, 0xf);   // row_shr:2
@@ -1005,9 +1091,15 @@ extern "C" {
 
 void gptk_camera(hipStream_t s, int grid, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses,
                  uint32_t seed0, float4* ray_o, float4* ray_d, float4* thr, float2* hit, float4* pass_rgb,
-                 unsigned* counts) {
+                 unsigned* counts, uint32_t* masks) {
+    // masks: numPixels words of scratch for the per-pixel sphere masks, or null (then, or with more than 32 spheres,
+    // every primary ray tests every sphere)
+    if (masks && (g->n_spheres < 1 || g->n_spheres > 32)) masks = nullptr;
+    if (masks)
+        hipLaunchKernelGGL(k_camera_masks, dim3((numPixels + GPT_BLOCK - 1) / GPT_BLOCK), dim3(GPT_BLOCK), 0, s, *g, *cam,
+                           numPixels, masks);
     hipLaunchKernelGGL(k_camera, dim3(grid), dim3(GPT_BLOCK), 0, s, *g, *cam, numPixels, numPasses, seed0, ray_o, ray_d,
-                       thr, hit, pass_rgb, counts);
+                       thr, hit, pass_rgb, counts, masks);
 }
 
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,

@@ -77,6 +77,31 @@ def test_primary_hits_with_lens():
     assert np.array_equal(t.view(np.int32), ref["hits"]["t"].view(np.int32))
 
 
+@pytest.mark.parametrize("kw", [dict(aperture=0.6), dict(aperture=0.3, radius=1.2), dict(fovx=120.0, pitch=1.2),
+                                dict(aperture=0.04, radius=0.45, yaw=1.0), dict(aperture=2.0, radius=2.5)])
+def test_primary_hits_with_per_pixel_sphere_masks(kw):
+    """Primary rays test only the spheres of their pixel's mask (k_camera_masks).  Wide lenses, a camera between the
+    spheres, one inside the lens' reach of a sphere, a wide field of view: ids and t still equal the full loop's, both
+    with one pass per launch (a wave = 64 neighbouring pixels) and with 64 (a wave = one pixel)."""
+    w, h = 192, 128
+    cam = S.orbit_camera(w, h, **kw)
+    sph = S.default_spheres()
+    with api.Scene(sph, None, api.render_params(max_depth=1, row_stride_is_width=1, passes_in_flight=64)) as sc:
+        prim, t = sc.primary_hits(cam, 3)
+        sc.reset(w * h)
+        sc.render_range(cam, 0, 64)
+        img, passes = sc.accum_download()
+    ref = O.render_pass(sph, None, cam, 3, O.params(max_depth=1, row_stride_is_width=1), want_hits=True)
+    assert np.array_equal(prim, ref["hits"]["prim"])
+    assert np.array_equal(t.view(np.int32), ref["hits"]["t"].view(np.int32))
+    assert (prim != -1).any()
+    # 64 passes in one launch: what one bounce contributes depends on the primary hit alone
+    acc = np.zeros((w * h, 3), dtype=np.float32)
+    for c in range(64):
+        acc += O.render_pass(sph, None, cam, c, O.params(max_depth=1, row_stride_is_width=1))["rgb"]
+    assert passes == 64 and parity.bits_equal(img, acc)
+
+
 @pytest.mark.parametrize("depth", [8, 30])
 def test_default_scene_pass(depth):
     """The reference's default scene (14 spheres, ground, sky), per-sample radiance."""
