@@ -1,4 +1,4 @@
-"""GPU: BASELINE-size configurations.  The oracle cannot render 2 M pixels x 1.5 M
+"""GPU: full-size configurations.  The oracle cannot render 2 M pixels x 1.5 M
 triangles in test time, so full-size runs are checked (a) against the oracle on strided
 pixel subsets (every pixel of a pass is independent of every other), (b) kd traversal
 against the device's own brute-force loop on the frame's primary rays, and (c) through
