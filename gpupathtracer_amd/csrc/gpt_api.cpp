@@ -165,6 +165,7 @@ struct gpt_scene {
     size_t spill_stride = 0;
     DevGeometry geom;
     int n_nodes = 0, n_refs = 0, tree_depth = 0;
+    int kd_small_used = 0;           // the SAH stage threshold the tree was built with
 
     // per-pixel / per-path buffers
     int numPixels = 0;
@@ -339,7 +340,7 @@ void gpt_render_params_default(gpt_render_params* p) {
     p->ground_enabled = 1;
     p->row_stride_is_width = 1;
     p->use_kdtree = 1;
-    p->kd_small_threshold = 24;
+    p->kd_small_threshold = 0;
     p->passes_in_flight = 0;
 }
 
@@ -355,7 +356,7 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
     if (params) rp = *params; else gpt_render_params_default(&rp);
     if (rp.max_depth < 0 || rp.max_depth > GPT_MAX_DEPTH)
         return fail(GPT_ERR_INVALID_ARGUMENT, "max_depth must be within 0..64");
-    if (rp.kd_small_threshold <= 0) rp.kd_small_threshold = 24;
+    if (rp.kd_small_threshold < 0) rp.kd_small_threshold = 0;   // 0: chosen per scene, see below
     if (rp.passes_in_flight < 0) rp.passes_in_flight = 0;
     if (rp.passes_in_flight > 512) rp.passes_in_flight = 512;
 
@@ -409,23 +410,43 @@ gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres, const Poly* p
         double tt0 = tnow();
         gptkd::Tree tree;
         gptkd::BuildParams bp;
-        bp.small_threshold = rp.kd_small_threshold;
         if (const char* e = getenv("GPT_KD_COST")) bp.traversal_cost = (float)atof(e);
         if (const char* e = getenv("GPT_KD_EMPTY_RATIO")) bp.empty_ratio = (float)atof(e);
         // large meshes are indexed on the GPU (the same tree, word for word); GPT_KD_BUILD=host|gpu overrides
         bool on_gpu = numPolys >= 200000;
         if (const char* e = getenv("GPT_KD_BUILD")) on_gpu = strcmp(e, "gpu") == 0;
-        if (on_gpu) {
-            std::string berr;
-            if (!gptkd::build_gpu(verts.data(), numPolys, bp, tree, &berr)) {
-                // asked for explicitly: report; chosen by size: the host builder gives the same tree
-                if (getenv("GPT_KD_BUILD")) { st = fail(GPT_ERR_HIP, berr); break; }
-                fprintf(stderr, "gpt_scene_create: %s; building the kd-tree on the host instead\n", berr.c_str());
-                (void)hipGetLastError();
-                gptkd::build(verts.data(), numPolys, bp, tree);
+        auto build_with = [&](int small_threshold, gptkd::Tree& out) -> gpt_status {
+            bp.small_threshold = small_threshold;
+            if (on_gpu) {
+                std::string berr;
+                if (!gptkd::build_gpu(verts.data(), numPolys, bp, out, &berr)) {
+                    // asked for explicitly: report; chosen by size: the host builder gives the same tree
+                    if (getenv("GPT_KD_BUILD")) return fail(GPT_ERR_HIP, berr);
+                    fprintf(stderr, "gpt_scene_create: %s; building the kd-tree on the host instead\n", berr.c_str());
+                    (void)hipGetLastError();
+                    on_gpu = false;
+                    gptkd::build(verts.data(), numPolys, bp, out);
+                }
+            } else {
+                gptkd::build(verts.data(), numPolys, bp, out);
             }
+            return GPT_OK;
+        };
+        if (rp.kd_small_threshold > 0) {
+            if ((st = build_with(rp.kd_small_threshold, tree))) break;
+            s->kd_small_used = rp.kd_small_threshold;
         } else {
-            gptkd::build(verts.data(), numPolys, bp, tree);
+            // Automatic: the stage threshold that is right for a surface mesh (median splits with empty-space cuts down
+            // to a dozen triangles) costs a volume of scattered triangles 10 % and vice versa.  Both trees are built and
+            // the one with the smaller expected traversal work -- surface-area rule, a node step weighted 4 and a
+            // triangle test 2.4, the weights that rank the measured kernel times of both kinds of scene -- is kept.
+            gptkd::Tree other;
+            if ((st = build_with(12, tree))) break;
+            if ((st = build_with(96, other))) break;
+            const double c12 = gptkd::expected_cost(tree, 4.0, 2.4), c96 = gptkd::expected_cost(other, 4.0, 2.4);
+            if (c96 < c12) std::swap(tree, other);
+            s->kd_small_used = c96 < c12 ? 96 : 12;
+            if (timing) fprintf(stderr, "gpt_scene_create: expected cost %.1f (SAH stage from 12) / %.1f (from 96)\n", c12, c96);
         }
         double tt1 = tnow();
         s->n_refs = (int)tree.refs.size();

@@ -403,6 +403,40 @@ void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out) {
     }
 }
 
+double expected_cost(const Tree& t, double node_cost, double tri_cost) {
+    struct Entry { uint32_t node; double lo[3], hi[3]; };
+    auto area = [](const double lo[3], const double hi[3]) {
+        const double dx = std::max(hi[0] - lo[0], 0.0), dy = std::max(hi[1] - lo[1], 0.0), dz = std::max(hi[2] - lo[2], 0.0);
+        return 2.0 * (dx * dy + dy * dz + dx * dz);
+    };
+    if (t.nodes.empty()) return 0.0;
+    Entry root;
+    root.node = 0;
+    for (int k = 0; k < 3; k++) { root.lo[k] = t.bounds[k]; root.hi[k] = t.bounds[3 + k]; }
+    const double a0 = area(root.lo, root.hi);
+    if (!(a0 > 0.0)) return 0.0;
+    double e_nodes = 0.0, e_tris = 0.0;
+    std::vector<Entry> stack;
+    stack.push_back(root);
+    while (!stack.empty()) {
+        const Entry e = stack.back();
+        stack.pop_back();
+        const Node& n = t.nodes[e.node];
+        const double p = area(e.lo, e.hi) / a0;
+        e_nodes += p;
+        const uint32_t axis = n.w0 & 3u;
+        if (axis == 3u) { e_tris += p * (double)n.w1; continue; }
+        float split;
+        std::memcpy(&split, &n.w1, 4);
+        Entry l = e, r = e;
+        l.node = n.w0 >> 2; l.hi[axis] = split;
+        r.node = (n.w0 >> 2) + 1u; r.lo[axis] = split;
+        stack.push_back(l);
+        stack.push_back(r);
+    }
+    return node_cost * e_nodes + tri_cost * e_tris;
+}
+
 void treelet_layout(const Tree& in, std::vector<Node>& out) {
     const std::vector<Node>& src = in.nodes;
     out.clear();

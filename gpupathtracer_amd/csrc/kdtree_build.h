@@ -30,6 +30,11 @@ struct Tree {
 // verts: n_tris x 9 floats (p0, p1, p2).
 void build(const float* verts, int n_tris, const BuildParams& bp, Tree& out);
 
+// Expected traversal work of a tree for a random line through its root box, by the surface-area rule: every node
+// counts with the chance that the line meets its region (region area / root area); returns
+// node_cost * E[nodes visited] + tri_cost * E[triangles tested].
+double expected_cost(const Tree& t, double node_cost, double tri_cost);
+
 // The same tree -- word for word -- built on the current HIP device (kdtree_build_gpu.hip): the level-by-level
 // decisions run as kernels, numbering by prefix sums in queue order.  false: a HIP call failed (*err says which).
 bool build_gpu(const float* verts, int n_tris, const BuildParams& bp, Tree& out, std::string* err);

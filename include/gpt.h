@@ -165,7 +165,8 @@ typedef struct gpt_render_params {
     /* 0: brute-force loop over every triangle, as the reference (:536-557).
      * 1: kd-tree traversal returning the same hit as that loop.               */
     int    use_kdtree;
-    int    kd_small_threshold; /* <= this many triangles: SAH stage (default 24; cukd: 64) */
+    int    kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64).  Default 0: automatic -- trees for 12 and
+                                * 96 are built and the one with the smaller expected traversal work is kept */
     /* Passes traced together by gpt_render_range: every kernel launch covers the
      * live paths of this many consecutive pass counters (at most 512).  Results
      * do not depend on it; throughput does (every launch ends in a tail of its

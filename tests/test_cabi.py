@@ -47,7 +47,7 @@ def test_render_params_defaults_are_the_reference_defines():
     assert p["ray_bias"] == np.float32(0.0002)                    # RAY_BIAS_DISTANCE
     assert p["min_ray_weight"] == 0.00001                         # MIN_RAY_WEIGHT (double)
     assert p["ground_elevation"] == np.float32(-0.8)              # HARD_CODED_GROUND_ELEVATION
-    assert p["ground_enabled"] == 1 and p["use_kdtree"] == 1 and p["kd_small_threshold"] == 24
+    assert p["ground_enabled"] == 1 and p["use_kdtree"] == 1 and p["kd_small_threshold"] == 0   # 0: chosen per scene
 
 
 def test_default_scene_and_presets_match_python_table():
