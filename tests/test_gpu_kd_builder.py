@@ -3,6 +3,7 @@ import time
 import numpy as np
 import pytest
 
+import scenes as S
 from gpupathtracer_amd import api, meshes
 
 pytestmark = pytest.mark.gpu
@@ -43,3 +44,19 @@ def test_gpu_builder_ten_million_triangles():
     """The largest baseline configuration: the 10 M-triangle soup of bench.py."""
     v, _ = meshes.random_soup(10000000, seed=12345, extent=1.0, edge=0.01)
     _compare(np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 9), 0)
+
+
+def test_sah_stage_threshold_is_chosen_per_scene():
+    """kd_small_threshold 0 (the default): the trees for 12 and 96 are built and the one with the smaller expected
+    traversal work is kept -- 12 for a surface mesh, 96 for a volume of scattered small triangles."""
+    cow, _ = meshes.load_asset("cow")
+    soup, _ = meshes.random_soup(60000, seed=2)
+    for verts, want in ((cow, 12), (soup, 96)):
+        polys = meshes.polys_from_triangles(verts, np.zeros((len(verts), 3), np.float32), S.MATERIALS["white"])
+        sizes = {}
+        for small in (0, 12, 96):
+            with api.Scene(None, polys, api.render_params(max_depth=1, kd_small_threshold=small)) as sc:
+                info = sc.info()
+                sizes[small] = (info["kd_nodes"], info["kd_refs"], info["kd_depth"])
+        assert sizes[12] != sizes[96]
+        assert sizes[0] == sizes[want], (sizes, want)
