@@ -56,6 +56,7 @@ SYMBOLS = {
     "gpt_debug_render_events": (_I, [_V, _V, _I, _V, _V, _V]),
     "gpt_debug_dump_queue": (_I, [_V, _V, _I, _I, _I, _V, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_uint)]),
     "gpt_debug_rng_uniforms": (_I, [_I, _V, _I, _I, _V]),
+    "gpt_debug_helpers": (_I, [_I, _I, _I, _V, _V]),
     "gpt_intersect_noalloc": (_I, [_V, _V, _I, _I, _V, _V]),
     "gpt_kdtree_build": (_I, [_V, _I, _I, c_void_pp]),
     "gpt_kdtree_build_gpu": (_I, [_V, _I, _I, _I, c_void_pp]),

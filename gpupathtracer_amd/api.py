@@ -193,6 +193,15 @@ def rng_uniforms(seeds, n_draws, device=0):
     return out
 
 
+def debug_helpers(fn, words_in, words_out, device=0):
+    """gpt_debug_helpers: helper function `fn` of the device code on n records of `words_in.shape[1]` words;
+    returns [n, words_out] uint32."""
+    words_in = np.ascontiguousarray(words_in, dtype=np.uint32)
+    out = np.empty((words_in.shape[0], int(words_out)), dtype=np.uint32)
+    _check(_lib.lib().gpt_debug_helpers(int(device), int(fn), words_in.shape[0], _ptr(words_in), _ptr(out)))
+    return out
+
+
 def accum_allreduce(scenes):
     """gpt_accum_allreduce: one RCCL sum of the scenes' accumulated images (one scene per GPU)."""
     arr = (ctypes.c_void_p * len(scenes))(*[sc._h for sc in scenes])

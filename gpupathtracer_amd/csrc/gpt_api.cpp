@@ -46,6 +46,7 @@ void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, cons
 void gptk_checksum(hipStream_t s, const uint32_t* words, size_t n, unsigned long long* out);
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats);
 void gptk_rng_uniforms(hipStream_t s, const uint32_t* seeds, int n_seeds, int n_draws, float* out);
+int gptk_debug_helpers(hipStream_t s, int fn, int n, const uint32_t* in, uint32_t* out, int* words_in, int* words_out);
 }
 
 namespace {
@@ -879,6 +880,31 @@ gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds
             st = fail(GPT_ERR_HIP, "rng kernel");
     }
     (void)hipFree(d_seeds);
+    (void)hipFree(d_out);
+    return st;
+}
+
+// The device's per-path helper functions on caller-given records (parity with the reference's own text).
+gpt_status gpt_debug_helpers(int device, int fn, int n, const uint32_t* in, uint32_t* out) {
+    if (!in || !out || n <= 0) return fail(GPT_ERR_INVALID_ARGUMENT, "bad argument");
+    int wi = 0, wo = 0;
+    if (gptk_debug_helpers(nullptr, fn, 0, nullptr, nullptr, &wi, &wo) != 0) return fail(GPT_ERR_INVALID_ARGUMENT, "unknown helper function");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GPT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(GPT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    GPT_ON_DEVICE(device);
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    gpt_status st = GPT_OK;
+    if (hipMalloc((void**)&d_in, (size_t)n * wi * 4) != hipSuccess || hipMalloc((void**)&d_out, (size_t)n * wo * 4) != hipSuccess) {
+        st = fail(GPT_ERR_OUT_OF_MEMORY, "helper buffers");
+    } else if (hipMemcpy(d_in, in, (size_t)n * wi * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        st = fail(GPT_ERR_HIP, "helper upload");
+    } else {
+        gptk_debug_helpers(nullptr, fn, n, d_in, d_out, nullptr, nullptr);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d_out, (size_t)n * wo * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            st = fail(GPT_ERR_HIP, "helper kernel");
+    }
+    (void)hipFree(d_in);
     (void)hipFree(d_out);
     return st;
 }

@@ -39,6 +39,7 @@ __device__ unsigned long long g_wave_iters[4];
 #include "gpt_device_structs.h"
 #include "kd_traverse.h"
 #include "pt_device.h"
+#include "pt_helper_eval.h"
 
 using namespace pt;
 
@@ -1060,6 +1061,31 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_rng_uniforms(const uint32_t* __re
     for (int k = 0; k < n_draws; k++) out[(size_t)s * (size_t)n_draws + (size_t)k] = rng.uniform();
 }
 
+// The per-path helper functions on caller-given records, for parity checks against outputs of the reference's own
+// text (record layouts: pt_helper_eval.h).  fn == HELPER_COUNT: the traversal kernel's form of the triangle test
+// (triangle_uvt, its two-comparison acceptance, and the hit key having to beat the key of "nothing hit yet", t = PT_T_START)
+// on the HELPER_TRIANGLE records: out = (accepted, t bits).
+__global__ __launch_bounds__(GPT_BLOCK) void k_debug_helpers(int fn, int n, int words_in, int words_out,
+                                                             const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    const int k = (int)(blockIdx.x * GPT_BLOCK + threadIdx.x);
+    if (k >= n) return;
+    const uint32_t* r = in + (size_t)k * (size_t)words_in;
+    uint32_t* o = out + (size_t)k * (size_t)words_out;
+    if (fn == HELPER_COUNT) {
+        const V3 a = helper_v3(r), b = helper_v3(r + 3), c = helper_v3(r + 6);
+        float b1, b2, t;
+        triangle_uvt(a, b - a, c - a, helper_v3(r + 9), helper_v3(r + 12), b1, b2, t);
+        const float least = vmin(vmin(b1, b2), 1.0f - (b1 + b2));
+        o[0] = (least >= 0.0f && t > 0.0f && hit_key(t, 0) < hit_key(PT_T_START, -1)) ? 1u : 0u;
+        o[1] = __float_as_uint(t);
+        return;
+    }
+    uint32_t rec[16], res[8];
+    for (int w = 0; w < words_in; w++) rec[w] = r[w];
+    helper_eval(fn, rec, res);
+    for (int w = 0; w < words_out; w++) o[w] = res[w];
+}
+
 // ---------------------------------------------------------------------------
 // Instrumentation and the scene checksum
 // ---------------------------------------------------------------------------
@@ -1167,6 +1193,17 @@ void gptk_gather_records(hipStream_t s, size_t n_refs, const int32_t* refs, cons
 void gptk_rng_uniforms(hipStream_t s, const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
     hipLaunchKernelGGL(k_rng_uniforms, dim3((unsigned)((n_seeds + GPT_BLOCK - 1) / GPT_BLOCK)), dim3(GPT_BLOCK), 0, s, seeds, n_seeds,
                        n_draws, out);
+}
+
+int gptk_debug_helpers(hipStream_t s, int fn, int n, const uint32_t* in, uint32_t* out, int* words_in, int* words_out) {
+    const int wi = fn == HELPER_COUNT ? helper_words_in(HELPER_TRIANGLE) : helper_words_in(fn);
+    const int wo = fn == HELPER_COUNT ? 2 : helper_words_out(fn);
+    if (words_in) *words_in = wi;
+    if (words_out) *words_out = wo;
+    if (wi == 0) return -1;
+    if (in && out && n > 0)
+        hipLaunchKernelGGL(k_debug_helpers, dim3((unsigned)((n + GPT_BLOCK - 1) / GPT_BLOCK)), dim3(GPT_BLOCK), 0, s, fn, n, wi, wo, in, out);
+    return 0;
 }
 
 void gptk_collect_wave_iters(hipStream_t s, unsigned long long* stats) {

@@ -426,6 +426,8 @@ PT_HD V3 direction_in_sphere(float xi1, float xi2) {
     sincos_f(around, s, c);
     return v3(up, c * over, s * over);
 }
+// computeReflectionDirection (:387-390): 2.0 * dot is a double product narrowed to float, i.e. an exact doubling.
+PT_HD V3 reflection_direction(V3 normal, V3 incident) { return (2.0f * dot(normal, incident)) * normal - incident; }
 // computeTransmissionDirection (:392-411); the radicand is formed in double.
 PT_HD V3 transmission_direction(V3 normal, V3 incident, float iorIncident, float iorTransmitted) {
     float cosTheta1 = dot(normal, incident);
@@ -527,7 +529,7 @@ PT_HD bool shade_bounce(V3& o, V3& d, V3& thr, int& medium,
         mediumTransmitted = -1;                // far side is air
     }
 
-    V3 reflectionDirection = (2.0f * dot(n, incident)) * n - incident;   // (:387-390)
+    V3 reflectionDirection = reflection_direction(n, incident);
     V3 transmissionDirection = transmission_direction(n, incident, iorIncident, iorTransmitted);
     V3 point = o + bestT * d;
     V3 biasVector = P.ray_bias * n;

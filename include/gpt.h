@@ -293,6 +293,19 @@ gpt_status gpt_debug_dump_queue(gpt_scene* scene, const Camera* camera, int coun
  * as used at path_tracer_kernel.cu:139-142, 492-493.  Host arrays. */
 gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds, int n_draws, float* out);
 
+/* The device's per-path helper functions on caller-given records (debug/parity): fn 0..11 =
+ * randhash, positionAlongRay, findGroundPlaneIntersection, FindTriangleIntersect,
+ * randomCosineWeightedDirectionInHemisphere, randomDirectionInSphere, computeReflectionDirection,
+ * computeTransmissionDirection, computeFresnel, the reflect / transmit / Fresnel chain of a surface
+ * hit, computeBackgroundColor, computeTransmission (path_tracer_kernel.cu:75-84, 194-475); fn 12 =
+ * the traversal kernel's form of the triangle test on fn 3's records (out: accepted as a hit closer than
+ * the initial 123456789, t).  `in` and
+ * `out` are HOST arrays of n records of 32-bit words; the record layouts (1/1, 7/3, 7/4, 15/4, 5/3,
+ * 2/3, 6/3, 8/3, 14/2, 8/8, 3/3, 4/3 and 15/2 words in / out) are those of
+ * oracle/ref_build/helpers_dump.cpp, which runs the reference's own text on the same inputs.
+ * Output words the library does not compute are 0xffffffff. */
+gpt_status gpt_debug_helpers(int device, int fn, int n, const uint32_t* in, uint32_t* out);
+
 /* gpt_debug_intersect for callers that cannot allocate device memory: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
  * no counterpart in the reference.  `d_rays` (n x 6 floats), `d_tri` and `d_t` (n

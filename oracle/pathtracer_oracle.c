@@ -6,15 +6,26 @@
  * checker in tests/, in __graft_entry__.smoke() and as bench.py's
  * cpu_baseline leg.  Nothing in the shipped library links or calls it.
  *
- * Pinning status: PARITY UNPINNED for the kernel path.  The reference ships no
- * tests, golden images or known-answer vectors, and its launcher cannot be built
- * in this image (it needs the CUDA toolkit headers; stand-ins are not written).
- * Pinned from outside this repository are only (1) the random numbers: the
- * generator below reproduces, bit for bit, tests/golden/thrust_rng.npz -- 64 seeds
- * x 4096 uniforms drawn from the real Thrust classes of the image's rocThrust --
- * and Thrust's documented 10000th minstd_rand value 399268537; (2) the mesh
- * inputs, tests/golden/obj_*.npz, produced by the reference's own OBJ loader.
- * Everything else rests on this restatement alone.
+ * Pinning status: PARTLY PINNED by the reference's own text.
+ *   Pinned, bit for bit, by outputs of code outside this repository:
+ *   (1) the helper functions -- orc_randhash, position_along_ray, ground_intersection,
+ *       triangle_intersect, cosine_weighted_direction, direction_in_sphere, reflection_direction,
+ *       transmission_direction, fresnel_reflection, background_color, transmission_color -- equal
+ *       tests/golden/ref_helpers.npz: the reference's path_tracer_kernel.cu lines 46-57, 75-84 and
+ *       194-475 compiled UNMODIFIED with g++ against the genuine CUDA toolkit headers of the image's
+ *       Triton wheel and the reference's own cutil_math.h (oracle/ref_build/helpers_dump.cpp), run
+ *       on 102 400 inputs per function (orc_helper_eval below is the test hook);
+ *   (2) the random numbers: the generator below reproduces tests/golden/thrust_rng.npz -- 64 seeds
+ *       x 4096 uniforms drawn from the real Thrust classes of the image's rocThrust -- and Thrust's
+ *       documented 10000th minstd_rand value 399268537;
+ *   (3) the mesh inputs, tests/golden/obj_*.npz, produced by the reference's own OBJ loader.
+ *   PARITY UNPINNED (they rest on this restatement alone; the reference ships no tests, golden
+ *   images or known-answer vectors): sphere_intersection (:250-281 -- under a host compiler its
+ *   min(t1,t2) / max(t1,t2) bind to cutil_math.h's host int min(int,int) and truncate, so a host
+ *   build of that text is not what the device build computes) and the bodies of the two kernels,
+ *   raycast_pixel (:125-191) and trace_path (:477-725), which need thrust/random.h (rocThrust
+ *   only builds under HIP, whose float3 clashes with the CUDA headers') -- i.e. the ORDER in
+ *   which the pinned helpers and random numbers are combined.
  *
  * Arithmetic follows what a host C++ compiler makes of the reference text:
  * double sub-expressions where a double literal or pow(float,int) appears,
@@ -620,4 +631,72 @@ void orc_set_num_threads(int n) {
 #else
     (void)n;
 #endif
+}
+
+/* ---- test hook: the helper functions on caller-given inputs -------------------
+ * Record layouts (32-bit words in / out) are those of oracle/ref_build/helpers_dump.cpp, which
+ * runs the reference's own text on the same inputs (tests/golden/ref_helpers.npz).  Returns 0,
+ * or -1 for an unknown name. */
+static f3 f3_at(const float* p) { return mk3(p[0], p[1], p[2]); }
+static void put3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+int orc_helper_eval(const char* name, int n, const uint32_t* in_words, uint32_t* out_words) {
+    const float* in = (const float*)in_words;
+    float* out = (float*)out_words;
+    for (int k = 0; k < n; k++) {
+        if (!strcmp(name, "randhash")) {
+            out_words[k] = orc_randhash(in_words[k]);
+        } else if (!strcmp(name, "position")) {
+            const float* r = in + 7 * (size_t)k;
+            Ray ray; ray.origin = f3_at(r); ray.direction = f3_at(r + 3);
+            put3(out + 3 * (size_t)k, position_along_ray(&ray, r[6]));
+        } else if (!strcmp(name, "ground")) {
+            const float* r = in + 7 * (size_t)k;
+            Ray ray; ray.origin = f3_at(r + 1); ray.direction = f3_at(r + 4);
+            f3 nrm = mk3(0, 0, 0);
+            out[4 * (size_t)k] = ground_intersection(r[0], &ray, &nrm);
+            put3(out + 4 * (size_t)k + 1, nrm);
+        } else if (!strcmp(name, "triangle")) {
+            const float* r = in + 15 * (size_t)k;
+            const uint32_t unset = 0x7fc0deadu;     /* what stays where the function returns before writing */
+            float tuv[3];
+            for (int c = 0; c < 3; c++) memcpy(&tuv[c], &unset, 4);
+            const uint32_t h = (uint32_t)triangle_intersect(f3_at(r), f3_at(r + 3), f3_at(r + 6), f3_at(r + 9), f3_at(r + 12),
+                                                            &tuv[0], &tuv[1], &tuv[2]);
+            memcpy(out_words + 4 * (size_t)k, &h, 4);
+            memcpy(out_words + 4 * (size_t)k + 1, tuv, 12);
+        } else if (!strcmp(name, "cosine")) {
+            const float* r = in + 5 * (size_t)k;
+            put3(out + 3 * (size_t)k, cosine_weighted_direction(f3_at(r), r[3], r[4]));
+        } else if (!strcmp(name, "sphere_dir")) {
+            put3(out + 3 * (size_t)k, direction_in_sphere(in[2 * (size_t)k], in[2 * (size_t)k + 1]));
+        } else if (!strcmp(name, "reflect")) {
+            const float* r = in + 6 * (size_t)k;
+            put3(out + 3 * (size_t)k, reflection_direction(f3_at(r), f3_at(r + 3)));
+        } else if (!strcmp(name, "transmit")) {
+            const float* r = in + 8 * (size_t)k;
+            put3(out + 3 * (size_t)k, transmission_direction(f3_at(r), f3_at(r + 3), r[6], r[7]));
+        } else if (!strcmp(name, "fresnel")) {
+            const float* r = in + 14 * (size_t)k;
+            const float R = fresnel_reflection(f3_at(r), f3_at(r + 3), r[6], r[7], f3_at(r + 11));
+            out[2 * (size_t)k] = R;
+            out[2 * (size_t)k + 1] = 1 - R;          /* :438 (0 on total internal reflection, :423) */
+        } else if (!strcmp(name, "surface")) {
+            const float* r = in + 8 * (size_t)k;
+            float* o = out + 8 * (size_t)k;
+            const f3 nrm = f3_at(r), inc = f3_at(r + 3);
+            const f3 R = reflection_direction(nrm, inc);
+            const f3 T = transmission_direction(nrm, inc, r[6], r[7]);
+            put3(o, R); put3(o + 3, T);
+            o[6] = fresnel_reflection(nrm, inc, r[6], r[7], T);
+            o[7] = 1 - o[6];
+        } else if (!strcmp(name, "background")) {
+            put3(out + 3 * (size_t)k, background_color(f3_at(in + 3 * (size_t)k)));
+        } else if (!strcmp(name, "transmission")) {
+            const float* r = in + 4 * (size_t)k;
+            put3(out + 3 * (size_t)k, transmission_color(f3_at(r), r[3]));
+        } else {
+            return -1;
+        }
+    }
+    return 0;
 }

@@ -10,6 +10,7 @@
 #include "../../gpupathtracer_amd/csrc/kd_traverse.h"
 #include "../../gpupathtracer_amd/csrc/kdtree_build.h"
 #include "../../gpupathtracer_amd/csrc/pt_device.h"
+#include "../../gpupathtracer_amd/csrc/pt_helper_eval.h"
 #include "../../include/gpt.h"
 
 using namespace pt;
@@ -252,6 +253,14 @@ void hh_rng_uniforms(const uint32_t* seeds, int n_seeds, int n_draws, float* out
         rng.seed(seeds[s]);
         for (int k = 0; k < n_draws; k++) out[(size_t)s * n_draws + k] = rng.uniform();
     }
+}
+
+// The per-path helper functions on caller-given records (layouts: pt_helper_eval.h); -1: unknown function.
+int hh_helper_eval(int fn, int n, const uint32_t* in, uint32_t* out) {
+    const int wi = pt::helper_words_in(fn), wo = pt::helper_words_out(fn);
+    if (wi == 0) return -1;
+    for (int k = 0; k < n; k++) pt::helper_eval(fn, in + (size_t)k * wi, out + (size_t)k * wo);
+    return 0;
 }
 
 void hh_camera_rays(const int32_t* pixel_ids, int n, int counter, const Camera* cam, int row_stride_is_width, float* out) {

@@ -9,6 +9,12 @@ needs /root/reference and /opt/rocm):
                                 uniform_real_distribution<float>(0,1) (the image's rocThrust) for 64
                                 seeds x 4096 draws
 
+  tests/golden/ref_helpers.npz  outputs of the REFERENCE's own text of the per-path helper functions
+                                (path_tracer_kernel.cu:46-57, 75-84, 194-475, compiled unmodified by
+                                oracle/ref_build/Makefile against the CUDA headers of the image's Triton
+                                wheel) for 102 400 inputs per function; the inputs are recomputed by
+                                tests/ref_helper_inputs.py, the file keeps their SHA-256
+
 Only outputs are stored: no source text of the reference enters the repository."""
 import os
 import struct
@@ -19,6 +25,8 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_helper_inputs  # noqa: E402
 REF = "/root/reference/GPUPathTracer"
 GOLD = os.path.join(ROOT, "tests", "golden")
 BIN = os.path.join(ROOT, "oracle", "_ref")
@@ -111,6 +119,26 @@ def main():
                             raw=np.stack(raw)[:, :64].copy(), uniform=np.stack(uni), minstd_10000th=np.uint32(kat))
         print("thrust_rng: %d seeds x %d draws; u == 1.0 occurs %d times, u == 0 %d times"
               % (n, nn, int((np.stack(uni) == 1.0).sum()), int((np.stack(uni) == 0.0).sum())))
+        helper_goldens(tmp)
+
+
+def helper_goldens(tmp):
+    exe = os.path.join(BIN, "helpers_dump")
+    if not os.path.isfile(exe):
+        print("ref_helpers: skipped (oracle/_ref/helpers_dump was not built: no CUDA headers in this image)")
+        return
+    arrays = {}
+    for name in ref_helper_inputs.FUNCTIONS:
+        n_in, n_out = ref_helper_inputs.LAYOUT[name]
+        words = ref_helper_inputs.make(name)
+        fin, fout = os.path.join(tmp, name + ".in"), os.path.join(tmp, name + ".out")
+        words.tofile(fin)
+        subprocess.check_call([exe, name, str(len(words)), fin, fout])
+        out = np.fromfile(fout, dtype="<u4").reshape(len(words), n_out)
+        arrays["out_" + name] = out
+        arrays["sha_" + name] = np.array(ref_helper_inputs.digest(words))
+        print("ref_helpers: %-12s %d records, %d words in / %d out" % (name, len(words), n_in, n_out))
+    np.savez_compressed(os.path.join(GOLD, "ref_helpers.npz"), **arrays)
 
 
 if __name__ == "__main__":
