@@ -339,3 +339,8 @@ def launch_kernel(num_polys, dev_polys, num_spheres, dev_spheres, num_pixels, co
 
 def launch_kernel_params(params):
     _lib.lib().gpt_launch_kernel_params(_ptr(params) if params is not None else None)
+
+
+def launch_kernel_static_scene(is_static):
+    """gpt_launch_kernel_static_scene: non-zero = launchKernel stops re-reading the scene arrays on every call."""
+    _lib.lib().gpt_launch_kernel_static_scene(int(is_static))

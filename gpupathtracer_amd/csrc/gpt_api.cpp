@@ -1244,7 +1244,7 @@ struct LaunchCache {
     LookAhead slot[2];
     Staged staged[2];
     size_t slot_floats = 0;
-    int last_counter = 0, streak = 0, calls_since_check = 0;
+    int last_counter = 0, streak = 0;
     Camera last_cam;
     bool have_last = false;
 } g_launch;
@@ -1277,9 +1277,17 @@ void drop_lookahead(LaunchCache& L, bool free_buffers) {
     if (free_buffers) L.slot_floats = 0;
 }
 
-// How often a run of calls with consecutive counters re-reads the scene arrays to see whether the
-// caller changed them behind unchanged pointers (every call outside such a run does).
-const int kChecksumEvery = 16;
+// The side stream, checksum words and events of the device the cache was set up on (none: a no-op).
+void release_side_resources(LaunchCache& L) {
+    if (L.device < 0) return;
+    DeviceGuard guard(L.device);
+    if (L.copy) { (void)hipStreamSynchronize(L.copy); (void)hipStreamDestroy(L.copy); L.copy = nullptr; }
+    if (L.d_sum) { (void)hipFree(L.d_sum); L.d_sum = nullptr; }
+    if (L.h_sum) { (void)hipHostFree(L.h_sum); L.h_sum = nullptr; }
+    for (LookAhead& a : L.slot) if (a.done) { (void)hipEventDestroy(a.done); a.done = nullptr; }
+    for (Staged& st : L.staged) if (st.done) { (void)hipEventDestroy(st.done); st.done = nullptr; }
+    L.device = -1;
+}
 }  // namespace
 
 void gpt_launch_kernel_params(const gpt_render_params* params) {
@@ -1315,6 +1323,7 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
             gpt_scene_destroy(L.scene);
             L.scene = nullptr;
         }
+        release_side_resources(L);     // (those of the GPU the caller was on before)
         hip_or_die(hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking), "stream");
         hip_or_die(hipMalloc((void**)&L.d_sum, 8), "hipMalloc");
         hip_or_die(hipHostMalloc((void**)&L.h_sum, 8, hipHostMallocDefault), "hipHostMalloc");
@@ -1324,13 +1333,13 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
     }
     const bool same_arrays = L.scene && L.polys == polys && L.spheres == spheres && L.numPolys == numPolys && L.numSpheres == numSpheres;
     const bool continues = L.have_last && same_camera(L.last_cam, renderCamera) && counter == L.last_counter + 1;
-    // Content checksum of the two device arrays: the scene is re-indexed only when it changes.  It runs on the
-    // side stream (the caller's own streams are not touched), on every call that does not continue a run of
-    // consecutive counters and on every kChecksumEvery-th call of such a run -- or never again once the
-    // caller has declared the scene static.
+    // Content checksum of the two device arrays: the scene is re-indexed only when it changes.  The reference reads
+    // the arrays on every call (path_tracer_kernel.cu:805), so a caller may edit them in place between two calls: the
+    // checksum -- one pass over the arrays on the side stream (the caller's own streams are not touched) and one
+    // wait -- runs on EVERY call, unless the caller has declared the scene static.  A mismatch drops every pass traced
+    // ahead from the old contents.
     bool same = same_arrays;
-    if (!same_arrays || (!L.assume_static && (!continues || ++L.calls_since_check >= kChecksumEvery))) {
-        L.calls_since_check = 0;
+    if (!same_arrays || !L.assume_static) {
         hip_or_die(hipMemsetAsync(L.d_sum, 0, 8, L.copy), "hipMemset");
         if (numPolys > 0) gptk_checksum(L.copy, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
         if (numSpheres > 0) gptk_checksum(L.copy, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);

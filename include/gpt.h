@@ -361,8 +361,9 @@ void       gpt_kdtree_free(gpt_kdtree* tree);
 /* up to passes_in_flight passes (32 by default here) traced ahead into two    */
 /* device buffers -- one being handed out, the next being traced -- and each    */
 /* call still returns exactly the pass `counter` names.  The arrays' contents   */
-/* are checksummed on every call outside such a run and on every 16th call      */
-/* inside one.                                                                  */
+/* are checksummed on EVERY call (the reference reads them on every call, so a  */
+/* caller may edit them in place): passes traced ahead from changed arrays are  */
+/* dropped.  gpt_launch_kernel_static_scene(1) switches the re-reading off.     */
 /* ------------------------------------------------------------------------- */
 #ifndef GPT_NO_POD_TYPES
 void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres,

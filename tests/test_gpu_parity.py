@@ -312,13 +312,27 @@ def test_launch_kernel_drop_in():
         api.device_upload(d_s, sph2)
         px2 = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 0, cam)
         assert not np.array_equal(px2, px0)
-        # ... also in the middle of a run of consecutive counters, where the arrays are re-read every 16th call only
+        # ... also in the middle of a run of consecutive counters, whose passes were traced ahead from the old
+        # contents: the very next call renders the new ones (the reference reads its arrays on every call)
         for c in range(1, 8):
             api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, c, cam)
         api.device_upload(d_s, sph)                          # back to the original spheres
-        late = [api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, c, cam) for c in range(8, 8 + 17)]
+        late = [api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, c, cam) for c in range(8, 8 + 5)]
         with api.Scene(sph, polys, api.render_params(max_depth=8, row_stride_is_width=0)) as sc:
-            assert np.array_equal(late[-1], sc.render_pass(cam, 8 + 16))
+            for k, px in enumerate(late):
+                assert np.array_equal(px, sc.render_pass(cam, 8 + k)), k
+        # a caller that declares the scene static is not re-read: stale by its own promise, then exact again
+        api.launch_kernel_static_scene(1)
+        try:
+            api.device_upload(d_s, sph2)
+            stale = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 13, cam)
+            with api.Scene(sph, polys, api.render_params(max_depth=8, row_stride_is_width=0)) as sc:
+                assert np.array_equal(stale, sc.render_pass(cam, 13))
+        finally:
+            api.launch_kernel_static_scene(0)
+        fresh = api.launch_kernel(polys.size, d_p, sph.size, d_s, w * h, 14, cam)
+        with api.Scene(sph2, polys, api.render_params(max_depth=8, row_stride_is_width=0)) as sc:
+            assert np.array_equal(fresh, sc.render_pass(cam, 14))
     finally:
         api.launch_kernel_params(None)
         api.device_free(d_s)
