@@ -174,7 +174,7 @@ __device__ __forceinline__ void analytic_hits_masked(const DevGeometry& g, V3 o,
 // ---------------------------------------------------------------------------
 // k_camera_masks: for every pixel, the spheres a primary ray of that pixel can possibly hit (bit s of masks[pixel]),
 // once per batch -- the camera is the same for all its passes -- so that k_camera tests one or two spheres per ray
-// instead of all of them.  Conservative by construction; a sphere left out is one no ray of the pixel reaches, so
+// instead of all of them.  Conservative: a sphere left out is one no ray of the pixel reaches, so
 // the rays' hits are those of the full loop.
 // The rays of a pixel: origin within `aperture` of the camera position, through a point of the focal plane within
 // rho = focal * (|horizontal| / (resx - 1) + |vertical| / (resy - 1)) of the pixel centre's (the jitter is half a pixel
@@ -207,9 +207,10 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera_masks(DevGeometry g, CamPr
         if (denom > 0.05f * Lc && len1 > 0.0f) {
             const float smax = (dist + R + a) / denom;
             const float reach = 1.01f * (R + a + smax * (rho + a)) + 1e-4f * (dist + R);
-            const float proj = dot(w, dirc) / len1;
-            const float perp2 = dist * dist - proj * proj;
-            keep = !(perp2 > reach * reach);                // (a NaN keeps the sphere)
+            // distance of the centre from the central line, as |w x dirc| / |dirc|: the cross product is exact to a few
+            // ulps of dist (dist^2 - proj^2 would cancel to ~1e-7 dist^2, more than a sub-pixel sphere's reach^2)
+            const float perp = length(cross(w, dirc)) / len1;
+            keep = !(perp > reach);                         // (a NaN keeps the sphere)
         }
         if (keep) mask |= 1u << s;
     }

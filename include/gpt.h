@@ -163,10 +163,26 @@ typedef struct gpt_render_params {
      * resolution.x (right for any image).  Identical for square images.       */
     int    row_stride_is_width;
     /* 0: brute-force loop over every triangle, as the reference (:536-557).
-     * 1: kd-tree traversal returning the same hit as that loop.               */
+     * 1: kd-tree traversal returning the same hit as that loop (triangle index
+     *    and the bits of t).  What that covers, asserted by the GPU tests
+     *    (tests/test_gpu_kd_exactness.py): every ray the renderer itself traces on
+     *    the benchmark configurations -- all rays entering depths 0..2 of a 1080p
+     *    frame of the 1.49 M-triangle cow, the primary rays of the other scenes --
+     *    ZERO differences.  Supported origin distance for arbitrary rays: 8 extents
+     *    of the mesh's bounding box.  Within it, rays aimed EXACTLY at mesh vertices
+     *    (the worst case) differ on at most 100 rays per million, and only where
+     *    the loop's own float arithmetic does not report a geometric intersection:
+     *    an edge-on silhouette triangle (determinant ~1e-11) whose test passes with
+     *    exact zeros and noise for t, which the ray misses -- or grazes somewhere
+     *    else -- in exact arithmetic.  The loop finds those because it tests every
+     *    triangle with every ray; a traversal only tests the triangles of the cells
+     *    the ray passes through up to its first hit.  Beyond 8 extents the count
+     *    grows about linearly with the distance.                                  */
     int    use_kdtree;
     int    kd_small_threshold; /* <= this many triangles: SAH stage (cukd: 64).  Default 0: automatic -- trees for 12 and
-                                * 96 are built and the one with the smaller expected traversal work is kept */
+                                * 96 are built and the one with the smaller expected traversal work is kept, which
+                                * doubles the build time and the peak host memory of gpt_scene_create (and of every
+                                * re-index launchKernel does after a scene change); name a threshold to build one tree */
     /* Passes traced together by gpt_render_range: every kernel launch covers the
      * live paths of this many consecutive pass counters (at most 512).  Results
      * do not depend on it; throughput does (every launch ends in a tail of its
@@ -185,8 +201,9 @@ void gpt_render_params_default(gpt_render_params* p);
 typedef struct gpt_scene gpt_scene;
 
 /* Upload `spheres`/`polys` (HOST arrays in the reference layout, the arrays
- * PathTracer::createDeviceData builds at path_tracer.cpp:116-278), build the
- * kd-tree over the polys on the host and upload its flattened form.
+ * PathTracer::createDeviceData builds at path_tracer.cpp:116-278) and build the
+ * kd-tree over the polys: on the host for small meshes, by kernels on `device`
+ * from 200 000 triangles (the same tree, word for word; see gpt_kdtree_build_gpu).
  * `device` is the HIP device ordinal. */
 gpt_status gpt_scene_create(const Sphere* spheres, int numSpheres,
                             const Poly* polys, int numPolys,
@@ -306,11 +323,15 @@ gpt_status gpt_debug_rng_uniforms(int device, const uint32_t* seeds, int n_seeds
  * Output words the library does not compute are 0xffffffff. */
 gpt_status gpt_debug_helpers(int device, int fn, int n, const uint32_t* in, uint32_t* out);
 
-/* gpt_debug_intersect for callers that cannot allocate device memory: code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
- * no counterpart in the reference.  `d_rays` (n x 6 floats), `d_tri` and `d_t` (n
- * entries each) are DEVICE pointers on the scene's GPU; results are those of
- * gpt_debug_intersect, bit for bit.  The call allocates and frees nothing: its ray
+/* gpt_debug_intersect for callers that cannot allocate device memory: tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * `d_rays` (n x 6 floats), `d_tri` and `d_t` (n entries each) are DEVICE pointers on
+ * the scene's GPU; results are those of gpt_debug_intersect, bit for bit.  The work
+ * runs on the scene's own non-blocking stream and the call waits for it
+ * (hipStreamSynchronize), so it is NOT for use inside a HIP graph capture; and since
+ * that stream does not order itself against the caller's streams, whatever writes
+ * d_rays must have FINISHED before the call (results are complete when it returns).
+ * The call allocates and frees nothing: its ray
  * queue, hit slots, counters and traversal-stack spill area live in one
  * file-scope device array of 8.6 MiB that every GPU the library runs on holds
  * until the process ends.  Limits (GPT_ERR_TOO_LARGE beyond them): at most

@@ -41,3 +41,14 @@ def families(v, rng, m):
     keepraw = np.zeros(m, bool); keepraw[3 * k:4 * k] = True      # the tiny-component family stays as it is
     d = np.where(keepraw[:, None], d, (d / nrm).astype(np.float32)).astype(np.float32)
     return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def aimed_at_vertices(v, rng, m, distance):
+    """m rays from a sphere of radius `distance` root-box extents around the mesh's centre, each aimed exactly at a vertex."""
+    pts = v.reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0); ctr, ext = (lo + hi) / 2, float((hi - lo).max())
+    u = rng.normal(size=(m, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = (ctr + u * ext * distance).astype(np.float32)
+    d = pts[rng.integers(0, len(pts), m)] - o
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([o, d], 1).astype(np.float32)

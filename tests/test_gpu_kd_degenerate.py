@@ -1,10 +1,10 @@
 """GPU: kd traversal == brute-force loop, bit for bit, on rays chosen to sit on the traversal's decision boundaries:
 origins on vertices (i.e. on split planes), axis-parallel directions, directions with zero / denormal / tiny components,
 rays aimed exactly at vertices and edge midpoints (equal-t ties between neighbouring triangles), against meshes whose
-triangles lie in axis-aligned planes and an ordinary one, at three scales.  Origins 10 000 extents away are included for
-the two meshes of large triangles only: from that far the brute-force loop's own float arithmetic starts to accept small
-triangles seen edge-on that the ray does not pass near (tools/kd_distance_sweep.py measures how often), which no
-traversal can reproduce."""
+triangles lie in axis-aligned planes and an ordinary one, at three scales.  Origins 10 000 extents away are asserted equal
+here for the two meshes of large triangles; for the monkey that family has its own test
+(tests/test_gpu_kd_exactness.py: from that far the brute-force loop's own float arithmetic starts to accept small
+triangles seen edge-on that the ray does not pass near, and the test certifies every differing ray as such a case)."""
 import numpy as np
 import pytest
 
@@ -24,7 +24,7 @@ def test_kd_equals_brute_force_on_boundary_rays(name):
         polys = meshes.polys_from_triangles(vv, n, S.MATERIALS["glass"])
         rays = families(vv, rng, 160000)
         if name == "monkey":
-            rays = rays[: 7 * (len(rays) // 8)]          # without the far-away family (see the module docstring)
+            rays = rays[: 7 * (len(rays) // 8)]          # the far-away family: test_gpu_kd_exactness.py
         for small in (0, 2):
             kw = {"kd_small_threshold": small} if small else {}
             with api.Scene(None, polys, api.render_params(max_depth=1, **kw)) as sc:

@@ -102,6 +102,38 @@ def test_primary_hits_with_per_pixel_sphere_masks(kw):
     assert passes == 64 and parity.bits_equal(img, acc)
 
 
+@pytest.mark.parametrize("aperture", [0.0, 0.04])
+def test_sphere_masks_keep_sub_pixel_spheres_at_4k(aperture):
+    """32 spheres of sub-pixel angular size, 20 to 120 units from the camera, at 3840 x 2160: the per-pixel masks
+    (k_camera_masks) must keep every sphere a ray of the pixel grazes.  Checked against the full loop on the device
+    itself: with a 33rd sphere (behind the camera, never hit) the masks are switched off and every ray tests every sphere."""
+    w, h = 3840, 2160
+    cam = S.orbit_camera(w, h, aperture=aperture)
+    eye = np.array(cam["position"], np.float32).reshape(3)
+    view = np.array(cam["view"], np.float32).reshape(3)
+    rng = np.random.default_rng(11)
+    sph = np.zeros(32, dtype=S.SPHERE_DTYPE)
+    right = np.cross(view, (0, 1, 0)); right /= np.linalg.norm(right)
+    up = np.cross(right, view)
+    for i in range(32):
+        dist = rng.uniform(20.0, 120.0)
+        # inside the frustum (half-angles 22.5 and ~12.9 degrees)
+        a, b = rng.uniform(-0.35, 0.35), rng.uniform(-0.2, 0.2)
+        d = view + a * right + b * up
+        sph[i]["position"] = eye + dist * d / np.linalg.norm(d)
+        sph[i]["radius"] = dist * 2.0e-4 * rng.uniform(0.3, 0.9)        # a pixel subtends 2.0e-4 rad
+        sph[i]["material"] = S.MATERIALS["red"]
+    more = np.concatenate([sph, sph[:1]])
+    more[32]["position"] = eye - 10.0 * view
+    rp = api.render_params(max_depth=1, ground_enabled=0)
+    with api.Scene(sph, None, rp) as sc:
+        prim, t = sc.primary_hits(cam, 0)
+    with api.Scene(more, None, rp) as sc:
+        prim_full, t_full = sc.primary_hits(cam, 0)
+    assert np.array_equal(prim, prim_full) and np.array_equal(t.view(np.int32), t_full.view(np.int32))
+    assert (prim_full >= 0).sum() >= 8, "the fixture must have rays that hit the tiny spheres"
+
+
 @pytest.mark.parametrize("depth", [8, 30])
 def test_default_scene_pass(depth):
     """The reference's default scene (14 spheres, ground, sky), per-sample radiance."""
