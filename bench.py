@@ -47,6 +47,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
+T_START = time.perf_counter()
 TRIS = [10000000]
 
 
@@ -107,7 +108,7 @@ def cpu_baseline(spheres, polys, cam, depth, target_seconds=40.0):
     }
 
 
-def cpu_kd_figure(spheres, polys, cam, depth, target_seconds=8.0):
+def cpu_kd_figure(spheres, polys, cam, depth, kd_small, target_seconds=8.0):
     """Context for the GPU / CPU ratio, NOT the reference's algorithm: the library's own per-path arithmetic and kd
     traversal (pt_device.h / kd_traverse.h compiled for the host by tests/host_harness, one lane at a time, OpenMP over
     pixels) on a strided pixel subset of the same pass.  Returns None when the harness has not been built."""
@@ -129,7 +130,7 @@ def cpu_kd_figure(spheres, polys, cam, depth, target_seconds=8.0):
     rp["ground_elevation"], rp["ground_enabled"], rp["row_stride_is_width"] = -0.8, 1, 1
     camv = np.array(cam, CAMERA_DTYPE).reshape(1)
     polys_c = np.ascontiguousarray(polys, dtype=POLY_DTYPE)
-    tree = H.hh_tree_build(P(verts), verts.shape[0], 24, ctypes.c_float(3.0))
+    tree = H.hh_tree_build(P(verts), verts.shape[0], int(kd_small), ctypes.c_float(3.0))   # the tree of the GPU run
     try:
         def run(stride):
             ys, xs = np.meshgrid(np.arange(stride // 2, h, stride), np.arange(stride // 2, w, stride), indexing="ij")
@@ -148,7 +149,7 @@ def cpu_kd_figure(spheres, polys, cam, depth, target_seconds=8.0):
         H.hh_tree_free(ctypes.c_void_p(tree))
     return {"value": tot / dt / 1e6, "unit": "Mpath-bounces/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
             "kind": "port", "what": "NOT the reference's algorithm: this library's kd traversal and shading arithmetic built for the host "
-            "(tests/host_harness), OpenMP over pixels",
+            "(tests/host_harness), OpenMP over pixels, on the tree of the GPU run (SAH stage from %d triangles)" % int(kd_small),
             "sample": "pass counter 0, every %dth pixel in x and y (%d paths, %d path-bounces, %.1f s)" % (stride, n, tot, dt)}
 
 
@@ -169,7 +170,8 @@ def parse_args(argv=None):
     ap.add_argument("--kd-small", type=int, default=0, help="kd builder: node size at which the SAH stage takes over (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spheres", action="store_true", help="ablation: drop the 14 spheres")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--traffic-file", default=None,
+                    help="stored rocprofv3 --pmc counters of this workload (default: profiles/traffic_<workload>.json)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launch and the sharding without a GPU: gloo ranks, no rendering (CPU tests)")
     return ap.parse_args(argv)
@@ -190,20 +192,35 @@ def spawn_ranks(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-    for ln in proc.stdout.splitlines():
-        if not ln.startswith("{"):
-            print(ln, file=sys.stderr)
-    if proc.returncode == 0:
+    env["PYTHONUNBUFFERED"] = "1"
+    print("bench.py: starting %d ranks (torch.distributed.run, RCCL)" % args.gpus, file=sys.stderr, flush=True)
+    # the ranks' stderr (their progress lines) is inherited and appears as it is written; stdout is read line by
+    # line: anything but rank 0's JSON line is passed on at once, so a long run is never silent
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    lines = []
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            print(ln, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0:
         if len(lines) != 1:
             print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
             return 1
-        if json.loads(lines[0]).get("n_gpus") != args.gpus:
-            print("bench.py: the ranks report n_gpus=%s, not %d" % (json.loads(lines[0]).get("n_gpus"), args.gpus), file=sys.stderr)
+        got = json.loads(lines[0])
+        if got.get("n_gpus") != args.gpus or (got.get("rccl") or {}).get("world_size") != args.gpus:
+            print("bench.py: the ranks report n_gpus=%s, RCCL world size %s, not %d"
+                  % (got.get("n_gpus"), (got.get("rccl") or {}).get("world_size"), args.gpus), file=sys.stderr)
             return 1
-        print(lines[0])
-    return proc.returncode
+        print(lines[0], flush=True)
+    return rc
+
+
+def progress(rank, world, what):
+    """One line per rank on stderr at the milestones of a run (a multi-GPU run is never silent for long)."""
+    print("bench.py: rank %d/%d %s (t = %.1f s)" % (rank, world, what, time.perf_counter() - T_START), file=sys.stderr, flush=True)
 
 
 def rank_passes(args, rank, world):
@@ -235,26 +252,31 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": args.scaling, "passes": [int(g[0]) for g in gathered],
-                          "ranges": [[int(g[1]), int(g[2])] for g in gathered]}))
+                          "ranges": [[int(g[1]), int(g[2])] for g in gathered],
+                          # (the group the collective layer formed: gloo here, RCCL in a real run)
+                          "rccl": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                   "backend": dist.get_backend() if world > 1 else None}}))
     if world > 1:
         dist.destroy_process_group()
 
 
-def load_traffic(path, match):
-    """HBM-side bytes per path-bounce of k_intersect_kd from a stored rocprofv3 --pmc collection --
-    only when that collection was made on the configuration of this run."""
+def load_traffic(path, match, kernel):
+    """Stored rocprofv3 --pmc figures of `kernel` (tools/collect_profiles.py) -- only when that collection was made on
+    the configuration of this run: (HBM-side bytes per path-bounce, counters dict, source note)."""
     if not os.path.exists(path):
-        return None, "no stored counters"
+        return None, None, "no stored counters (%s)" % os.path.relpath(path, ROOT)
     try:
         tj = json.load(open(path))
     except Exception:
-        return None, "unreadable " + os.path.basename(path)
+        return None, None, "unreadable " + os.path.basename(path)
     cfg = tj.get("config")
     if cfg != match:
-        return None, "stored counters are for another configuration (%s)" % json.dumps(cfg)
-    if not tj.get("k_intersect_hbm_bytes_per_launch") or not tj.get("path_bounces_per_launch"):
-        return None, "incomplete " + os.path.basename(path)
-    return tj["k_intersect_hbm_bytes_per_launch"] / tj["path_bounces_per_launch"], \
+        return None, None, "stored counters are for another configuration (%s)" % json.dumps(cfg)
+    k = (tj.get("kernels") or {}).get(kernel)
+    if not k or not k.get("hbm_bytes_per_launch") or not k.get("path_bounces_per_launch"):
+        return None, None, "incomplete " + os.path.basename(path)
+    counters = {n: k[n] for n in ("valu_busy", "valu_lane_utilisation", "l2_hit_rate", "wave_cycles_waiting") if n in k}
+    return k["hbm_bytes_per_launch"] / k["path_bounces_per_launch"], counters, \
         "stored: %s (%s), not measured in this run" % (os.path.relpath(path, ROOT), tj.get("source", "rocprofv3 --pmc"))
 
 
@@ -291,6 +313,7 @@ def main(argv=None):
     if distributed:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    progress(rank, world, "on device %d, RCCL group %s" % (local_rank, "up" if distributed else "not used"))
     TRIS[0] = args.tris
     spheres, polys = build_workload(args.workload, args.subdiv)
     if args.no_spheres:
@@ -324,8 +347,10 @@ def main(argv=None):
     tris_per_pb = st["kd_tris_tested"] / pb1
     hit_frac = st["hits"] / pb1
     scene.set_profiling(time_kernels=False, count_kd_work=False)
+    progress(rank, world, "scene ready (%.1f s), warm-up of %d passes starts" % (t_build, we - wb))
     scene.render_range(cam, wb, we)
     scene.reset(n_pix)
+    progress(rank, world, "warm-up done, timing passes %d..%d" % (tb, te))
     scene.set_profiling(time_kernels=True, count_kd_work=False)
 
     image = sharding.scene_image_tensor(scene, torch.device("cuda", local_rank))
@@ -338,16 +363,21 @@ def main(argv=None):
     barrier()
     elapsed = time.perf_counter() - t0
 
+    progress(rank, world, "timed region done: %.2f s" % elapsed)
     st = scene.stats()
     t = torch.tensor([elapsed, float(st["path_bounces"]), float(my_passes)], dtype=torch.float64, device="cuda")
     if distributed:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed_max, total_pb, total_passes = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2])))
+        elapsed_min = float(tmin[0])
     else:
         elapsed_max, total_pb, total_passes = elapsed, float(st["path_bounces"]), my_passes
+        elapsed_min = elapsed
     # every pass of the job is in the reduced image exactly once (its 4th channel counts them)
     passes_in_image = int(round(float(image[3].item())))
     if passes_in_image != total_passes:
@@ -382,10 +412,10 @@ def main(argv=None):
         counter_config = {"workload": args.workload, "subdiv": args.subdiv if args.workload == "cow_heavy" else None,
                           "tris": 0 if polys is None else int(polys.size), "width": args.width, "height": args.height,
                           "depth": args.depth, "passes_per_launch": batch, "kd": info}
-        if kernel == "k_intersect_kd":
-            per_pb, traffic_source = load_traffic(args.traffic_file, counter_config)
-            if per_pb is not None:
-                traffic = per_pb * pb_per_launch
+        traffic_file = args.traffic_file or os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        per_pb, counters, traffic_source = load_traffic(traffic_file, counter_config, kernel)
+        if per_pb is not None:
+            traffic = per_pb * pb_per_launch
         # A workload whose algorithmic bytes exceed what HBM could deliver in the measured time is served
         # from the caches: its bound is the vector ALU, and an HBM fraction would say nothing.
         cache_resident = achieved > HBM_PEAK_GBS
@@ -401,6 +431,8 @@ def main(argv=None):
             "counter_config": counter_config,
             # measured HBM-side bytes over the kernel's time over the peak (needs stored counters of this configuration)
             "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
+            # the kernel's stored SQ / TCC figures: VALU issue-slot occupancy, lane activity, L2 hit rate, waiting share
+            "counters": counters,
             "algorithmic_gbps": achieved,
             "bytes_per_path_bounce": kernel_bytes,
             "pass_level": {"bytes_per_path_bounce": bytes_per_pb, "algorithmic_gbps": pass_level,
@@ -415,7 +447,7 @@ def main(argv=None):
         }
         if cache_resident:
             roofline["note"] = ("algorithmic bytes exceed what HBM could deliver in that time: the scene is cache resident and "
-                                "the kernel VALU-bound; see profiles/ for its VALU utilisation")
+                                "the kernel VALU-bound; its VALU occupancy and lane activity are in `counters`")
         out = {
             "metric": "Mpath-bounces/s",
             "value": total_pb / elapsed_max / 1e6,
@@ -448,10 +480,16 @@ def main(argv=None):
                 "kd": dict(info, build_and_upload_s=round(t_build, 2)),
             },
             "roofline": roofline,
+            # what the collective layer itself saw: the group RCCL formed, and the one sum-reduce of the float4 images
+            "rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "reduced_bytes": int(image.numel() * image.element_size()), "collectives_in_timed_region": 1} if distributed
+                    else {"world_size": 1, "backend": None, "reduced_bytes": 0, "collectives_in_timed_region": 0},
+            # load balance: the timed region of the fastest and the slowest rank (value uses the slowest)
+            "rank_elapsed_s": {"min": elapsed_min, "max": elapsed_max},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(spheres, polys if polys is not None else None, cam, args.depth)
-            kd_fig = cpu_kd_figure(spheres, polys, cam, args.depth)
+            kd_fig = cpu_kd_figure(spheres, polys, cam, args.depth, scene.kd_small_threshold())
             if kd_fig is not None:
                 out["cpu_kd_traversal"] = kd_fig
         print(json.dumps(out))

@@ -48,6 +48,8 @@ SYMBOLS = {
     "gpt_accum_download": (_I, [_V, _V, ctypes.POINTER(_I)]),
     "gpt_accum_upload": (_I, [_V, _V, _I]),
     "gpt_accum_allreduce": (_I, [c_void_pp, _I]),
+    "gpt_shutdown": (_I, []),
+    "gpt_scene_kd_small_threshold": (_I, [_V, ctypes.POINTER(_I)]),
     "gpt_get_stats": (_I, [_V, ctypes.POINTER(GptStats)]),
     "gpt_scene_set_profiling": (_I, [_V, _I, _I]),
     "gpt_scene_info": (_I, [_V, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
@@ -75,6 +77,9 @@ SYMBOLS = {
     "gpt_default_scene_sphere_count": (_I, []),
     "gpt_default_scene": (None, [_V]),
     "gpt_material_preset": (_I, [ctypes.c_char_p, _V]),
+    "gpt_scene_preset_count": (_I, []),
+    "gpt_scene_preset_name": (ctypes.c_char_p, [_I]),
+    "gpt_scene_preset": (_I, [ctypes.c_char_p, ctypes.c_char_p, c_void_pp, ctypes.POINTER(_I), c_void_pp, ctypes.POINTER(_I), _V]),
     "gpt_orbit_camera": (None, [_F, _F, _F, _F, _F, _F, _F, _V, _V]),
     "gpt_default_camera": (None, [_F, _F, _V]),
     "gpt_tonemap_8bit": (None, [_V, _I, _I, _V]),

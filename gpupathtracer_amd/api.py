@@ -147,6 +147,12 @@ class Scene:
         _check(_lib.lib().gpt_scene_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
         return {"kd_nodes": a.value, "kd_refs": b.value, "kd_depth": c.value, "passes_in_flight": d.value}
 
+    def kd_small_threshold(self):
+        """gpt_scene_kd_small_threshold: the SAH stage threshold the scene's tree was built with."""
+        v = ctypes.c_int()
+        _check(_lib.lib().gpt_scene_kd_small_threshold(self._h, ctypes.byref(v)))
+        return v.value
+
     def primary_hits(self, camera, counter):
         cam = _cam(camera)
         n = self._ensure(cam)
@@ -200,6 +206,11 @@ def debug_helpers(fn, words_in, words_out, device=0):
     out = np.empty((words_in.shape[0], int(words_out)), dtype=np.uint32)
     _check(_lib.lib().gpt_debug_helpers(int(device), int(fn), words_in.shape[0], _ptr(words_in), _ptr(out)))
     return out
+
+
+def shutdown():
+    """gpt_shutdown: RCCL communicators and launchKernel's cache released."""
+    _check(_lib.lib().gpt_shutdown())
 
 
 def accum_allreduce(scenes):
@@ -264,6 +275,31 @@ def material_preset(name):
     m = np.zeros(1, dtype=MATERIAL_DTYPE)
     _check(_lib.lib().gpt_material_preset(name.encode(), _ptr(m)))
     return m[0]
+
+
+def scene_preset_names():
+    L = _lib.lib()
+    return [L.gpt_scene_preset_name(i).decode() for i in range(L.gpt_scene_preset_count())]
+
+
+def scene_preset(name, mesh_dir=None):
+    """gpt_scene_preset: (spheres, polys or None, view dict for orbit_camera) of a named scene."""
+    L = _lib.lib()
+    ps, pp = ctypes.c_void_p(), ctypes.c_void_p()
+    ns, npoly = ctypes.c_int(), ctypes.c_int()
+    view = np.zeros(8, dtype=np.float32)
+    _check(L.gpt_scene_preset(name.encode(), mesh_dir.encode() if mesh_dir else None, ctypes.byref(ps), ctypes.byref(ns),
+                              ctypes.byref(pp), ctypes.byref(npoly), _ptr(view)))
+    try:
+        spheres = np.frombuffer(bytes((ctypes.c_char * (ns.value * SPHERE_DTYPE.itemsize)).from_address(ps.value)),
+                                dtype=SPHERE_DTYPE).copy() if ns.value else np.zeros(0, SPHERE_DTYPE)
+        polys = np.frombuffer(bytes((ctypes.c_char * (npoly.value * POLY_DTYPE.itemsize)).from_address(pp.value)),
+                              dtype=POLY_DTYPE).copy() if npoly.value else None
+    finally:
+        L.gpt_free(ps)
+        L.gpt_free(pp)
+    return spheres, polys, {"yaw": float(view[0]), "pitch": float(view[1]), "radius": float(view[2]), "aperture": float(view[3]),
+                            "fovx": float(view[4]), "center": tuple(float(x) for x in view[5:8])}
 
 
 def orbit_camera(width, height, fovx=45.0, yaw=0.0, pitch=0.3, radius=4.0, aperture=0.04, center=(0, 0, 0)):

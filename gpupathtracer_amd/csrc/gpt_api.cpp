@@ -745,6 +745,12 @@ gpt_status gpt_scene_info(gpt_scene* s, int* n_nodes, int* n_refs, int* tree_dep
     return GPT_OK;
 }
 
+gpt_status gpt_scene_kd_small_threshold(gpt_scene* s, int* out) {
+    if (!s || !out) return fail(GPT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = s->kd_small_used;
+    return GPT_OK;
+}
+
 gpt_status gpt_debug_primary_hits(gpt_scene* s, const Camera* cam, int counter, int32_t* prim, float* t) {
     gpt_status st = check_render_args(s, cam);
     if (st) return st;
@@ -1061,6 +1067,26 @@ gpt_status gpt_accum_allreduce(gpt_scene* const* scenes, int n) {
     return st;
 }
 
+// Ends what the library keeps for the process: the RCCL communicators of gpt_accum_allreduce and launchKernel's cached
+// scene, side stream and staging buffers.  Scenes the caller created stay the caller's to destroy.
+void gpt_shutdown_launch_cache_();
+gpt_status gpt_shutdown(void) {
+    gpt_shutdown_launch_cache_();
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    Rccl& R = *rccl();
+    gpt_status st = GPT_OK;
+    for (auto& entry : g_comms) {
+        for (size_t i = 0; i < entry.second.size(); i++) {
+            if (!entry.second[i]) continue;
+            DeviceGuard guard(entry.first[i]);
+            const int rc = R.ok ? R.CommDestroy(entry.second[i]) : 0;
+            if (rc != 0) st = fail(GPT_ERR_HIP, std::string("ncclCommDestroy: ") + R.GetErrorString(rc));
+        }
+    }
+    g_comms.clear();
+    return st;
+}
+
 // ---- closest-hit query that allocates nothing -----------------------------------
 // gpt_intersect_noalloc: gpt_debug_intersect for callers that cannot allocate device memory.
 // Everything the query needs beyond its inputs and outputs -- the ray queue in the kernels'
@@ -1301,6 +1327,23 @@ void gpt_launch_kernel_params(const gpt_render_params* params) {
         gpt_scene_destroy(g_launch.scene);
         g_launch.scene = nullptr;
     }
+}
+
+void gpt_shutdown_launch_cache_() {
+    std::lock_guard<std::mutex> lock(g_launch.mu);
+    LaunchCache& L = g_launch;
+    if (L.scene) {
+        DeviceGuard guard(L.scene->device);
+        (void)hipStreamSynchronize(L.scene->stream);
+        drop_lookahead(L, true);
+        gpt_scene_destroy(L.scene);
+        L.scene = nullptr;
+    } else if (L.device >= 0) {
+        DeviceGuard guard(L.device);
+        drop_lookahead(L, true);
+    }
+    release_side_resources(L);
+    L.have_last = false;
 }
 
 void gpt_launch_kernel_static_scene(int is_static) {

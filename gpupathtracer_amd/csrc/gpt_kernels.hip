@@ -182,6 +182,11 @@ __device__ __forceinline__ void analytic_hits_masked(const DevGeometry& g, V3 o,
 // |1 - s| * aperture + s * rho away from it.  A ray that meets the sphere (centre C, radius R) does so at a point whose
 // central-ray counterpart is within C's distance + R + that deviation of the camera, which bounds s; the sphere is kept
 // when its centre is no further from the central LINE than R + the deviation at that s (1 % and a little added).
+// R here is not the sphere's radius but the radius the reference's float arithmetic gives it: its test forms
+// (v . d)^2 - (v . v - r^2) from terms of the size of dist^2, whose roundings add up to at most ~7e-7 dist^2 -- for a
+// sphere far away that is more than r^2 itself, and rays passing the sphere at up to sqrt(r^2 + 7e-7 dist^2) from its
+// centre can pass the test (measured at 3840 x 2160: 2e-7 dist^2; a sphere of a third of a pixel 50 units away is "hit"
+// from five pixels away).  The masks must keep what the loop hits, so they use sqrt(r^2 + 2e-6 dist^2).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(GPT_BLOCK) void k_camera_masks(DevGeometry g, CamPre cam, int numPixels,
                                                             uint32_t* __restrict__ masks) {
@@ -202,7 +207,9 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera_masks(DevGeometry g, CamPr
     for (int s = 0; s < n; s++) {
         const float4 sp = g.spheres[s];
         const V3 w = v3(sp.x, sp.y, sp.z) - cam.position;
-        const float R = sqrtf(sp.w), dist = length(w);
+        const float dist = length(w);
+        const float dmax = dist + a;                            // no origin of the pixel's rays is further from the centre
+        const float R = sqrtf(sp.w + 2.0e-6f * dmax * dmax);    // the radius of the reference's float test (see above)
         bool keep = true;
         if (denom > 0.05f * Lc && len1 > 0.0f) {
             const float smax = (dist + R + a) / denom;

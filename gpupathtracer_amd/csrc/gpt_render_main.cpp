@@ -17,14 +17,16 @@ static void usage() {
             "usage: gpt_render [--width W] [--height H] [--spp N] [--depth D] [--out image.ppm] [--pfm image.pfm] [--exr image.exr]\n"
             "                  [--obj mesh.obj [--material NAME] [--scale S] [--translate X Y Z]] [--no-spheres]\n"
             "                  [--yaw R] [--pitch R] [--radius R] [--aperture R] [--fovx DEG] [--center X Y Z]\n"
-            "                  [--brute-force] [--device N] [--gpus N]\n"
+            "                  [--scene NAME --assets DIR] [--brute-force] [--device N] [--gpus N]\n"
+            "  --scene NAME: one of the named scenes (Default, CornellBox, Diamond-NoDOF, Monkey, Speed, Subsurface); DIR holds\n"
+            "            the reference's .obj files.  Sets the spheres, the meshes and the camera; later flags override the camera\n"
             "  --gpus N: the spp passes are split across devices 0..N-1 (one host thread and one scene per GPU,\n"
             "            disjoint ranges of pass counters) and the images summed with one RCCL all-reduce\n");
 }
 
 int main(int argc, char** argv) {
     int width = 512, height = 512, spp = 64, depth = 30, device = 0, gpus = 0;   // display.cpp:33-34, MAX_TRACE_DEPTH
-    std::string out = "render.ppm", pfm, exr, obj, material = "glass";
+    std::string out = "render.ppm", pfm, exr, obj, material = "glass", scene_name, assets;
     float scale = 1, tr[3] = {0, 0, 0};
     float yaw = 0, pitch = 0.3f, radius = 4, aperture = 0.04f, fovx = 45, center[3] = {0, 0, 0};
     bool spheres_on = true, brute = false;
@@ -41,6 +43,8 @@ int main(int argc, char** argv) {
         else if (a == "--pfm") { need(1); pfm = argv[++i]; }
         else if (a == "--exr") { need(1); exr = argv[++i]; }
         else if (a == "--obj") { need(1); obj = argv[++i]; }
+        else if (a == "--scene") { need(1); scene_name = argv[++i]; }
+        else if (a == "--assets") { need(1); assets = argv[++i]; }
         else if (a == "--material") { need(1); material = argv[++i]; }
         else if (a == "--scale") { need(1); scale = (float)atof(argv[++i]); }
         else if (a == "--translate") { need(3); for (int k = 0; k < 3; k++) tr[k] = (float)atof(argv[++i]); }
@@ -60,7 +64,34 @@ int main(int argc, char** argv) {
     if (spheres_on) { spheres.resize((size_t)gpt_default_scene_sphere_count()); gpt_default_scene(spheres.data()); }
     Poly* polys = nullptr;
     int numPolys = 0;
-    if (!obj.empty()) {
+    if (!scene_name.empty()) {
+        // a named scene: its spheres, meshes and camera; camera flags given AFTER --scene on the command line override it
+        Sphere* ps = nullptr;
+        int ns = 0;
+        gpt_preset_view view;
+        if (gpt_scene_preset(scene_name.c_str(), assets.empty() ? nullptr : assets.c_str(), &ps, &ns, &polys, &numPolys, &view) != GPT_OK) {
+            fprintf(stderr, "%s\n", gpt_last_error());
+            return 1;
+        }
+        spheres.assign(ps, ps + ns);
+        gpt_free(ps);
+        bool seen = false;
+        bool set_yaw = false, set_pitch = false, set_radius = false, set_aperture = false, set_fovx = false, set_center = false;
+        for (int i = 1; i < argc; i++) {
+            std::string a = argv[i];
+            if (a == "--scene") seen = true;
+            if (!seen) continue;
+            set_yaw |= a == "--yaw"; set_pitch |= a == "--pitch"; set_radius |= a == "--radius";
+            set_aperture |= a == "--aperture"; set_fovx |= a == "--fovx"; set_center |= a == "--center";
+        }
+        if (!set_yaw) yaw = view.yaw;
+        if (!set_pitch) pitch = view.pitch;
+        if (!set_radius) radius = view.radius;
+        if (!set_aperture) aperture = view.apertureRadius;
+        if (!set_fovx) fovx = view.fovx_degrees;
+        if (!set_center) for (int k = 0; k < 3; k++) center[k] = view.center[k];
+        printf("Scene %s: %d spheres, %d triangles\n", scene_name.c_str(), ns, numPolys);
+    } else if (!obj.empty()) {
         Material m;
         if (gpt_material_preset(material.c_str(), &m) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
         float bbox[6];
@@ -130,6 +161,7 @@ int main(int argc, char** argv) {
     if (!pfm.empty() && gpt_write_pfm(pfm.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     if (!exr.empty() && gpt_write_exr(exr.c_str(), img.data(), width, height, passes) != GPT_OK) { fprintf(stderr, "%s\n", gpt_last_error()); return 1; }
     for (gpt_scene* sc : scenes) gpt_scene_destroy(sc);
+    gpt_shutdown();      // the RCCL communicators of --gpus
     gpt_free(polys);
     return 0;
 }

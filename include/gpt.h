@@ -247,6 +247,11 @@ gpt_status gpt_accum_upload(gpt_scene* scene, const float* host_rgb, int passes)
  * The scenes must be on n different devices and have the same pixel count.
  * RCCL (librccl.so) is loaded on first use. */
 gpt_status gpt_accum_allreduce(gpt_scene* const* scenes, int n);
+/* Releases what the library keeps for the life of the process: the RCCL communicators
+ * gpt_accum_allreduce caches per device list (ncclCommDestroy) and launchKernel's cached scene,
+ * side stream and staging buffers.  Scenes created by the caller are not touched.  The library
+ * can be used again afterwards (everything is set up again on demand). */
+gpt_status gpt_shutdown(void);
 
 /* Work counters since the last gpt_scene_reset. */
 typedef struct gpt_stats {
@@ -277,6 +282,9 @@ gpt_status gpt_scene_set_profiling(gpt_scene* scene, int time_kernels, int count
 /* Size of the scene's kd-tree, and the number of passes traced together per
  * launch that the last gpt_scene_reset settled on (0 before the first one). */
 gpt_status gpt_scene_info(gpt_scene* scene, int* n_nodes, int* n_refs, int* tree_depth, int* passes_in_flight);
+
+/* The SAH stage threshold the scene's kd-tree was built with (what kd_small_threshold = 0 chose). */
+gpt_status gpt_scene_kd_small_threshold(gpt_scene* scene, int* out);
 
 /* First-hit record of every primary ray of pass `counter` (debug/parity):
  * prim[i] = -1 miss, -2 ground, 0x40000000|s sphere s, otherwise triangle
@@ -427,6 +435,23 @@ void gpt_default_scene(Sphere* out_spheres /* 14 entries */);
  * "lightBlue", "gold", "steel", "light").  Returns GPT_ERR_INVALID_ARGUMENT
  * for an unknown name. */
 gpt_status gpt_material_preset(const char* name, Material* out);
+
+/* Named scenes.  The reference was shipped as five executables -- "CornellBox", "Diamond-NoDOF",
+ * "Monkey", "Speed", "Subsurface" -- each made by editing the scene table, the mesh path and the
+ * camera in the source (path_tracer.cpp:54, 116-278); only the names survive, the committed source is
+ * the 14-sphere scene ("Default").  A preset restates what its name says with the reference's meshes
+ * (`mesh_dir`: the directory holding box.obj, diamond.obj, monkey.obj, coil.obj; may be NULL for
+ * "Default" and "Speed"), material presets and sphere table; placements are this library's.
+ * *out_spheres / *out_polys are malloc'ed (free with gpt_free; NULL when the scene has none);
+ * out_view (may be NULL) receives the orbit-camera parameters for gpt_orbit_camera. */
+typedef struct gpt_preset_view {
+    float yaw, pitch, radius, apertureRadius, fovx_degrees;
+    float center[3];
+} gpt_preset_view;
+int         gpt_scene_preset_count(void);
+const char* gpt_scene_preset_name(int index);
+gpt_status  gpt_scene_preset(const char* name, const char* mesh_dir, Sphere** out_spheres, int* out_numSpheres,
+                             Poly** out_polys, int* out_numPolys, gpt_preset_view* out_view);
 
 /* InteractiveCamera defaults + buildRenderCamera (interactive_camera.cpp:15-25,
  * 66-87; display.cpp:78-85): orbit camera around `center`. */

@@ -165,6 +165,61 @@ def test_obj_loader_semantics(tmp_path):
     assert polys["material"][0] == np.array(S.MATERIALS["marble"], MATERIAL_DTYPE)
 
 
+def write_obj(path, verts, normals):
+    """A triangle soup as an OBJ file the reference's loader reads back exactly: `v` and `vn` lines with 9 significant
+    digits (float32 round trip), one `f v//n` line per triangle, single spaces, LF endings."""
+    verts = np.asarray(verts, np.float32).reshape(-1, 3, 3)
+    normals = np.asarray(normals, np.float32).reshape(-1, 3)
+    with open(path, "w") as f:
+        for tri in verts:
+            for v in tri:
+                f.write("v %.9g %.9g %.9g\n" % tuple(float(x) for x in v))
+        for n in normals:
+            f.write("vn %.9g %.9g %.9g\n" % tuple(float(x) for x in n))
+        for i in range(len(verts)):
+            f.write("f %d//%d %d//%d %d//%d\n" % (3 * i + 1, i + 1, 3 * i + 2, i + 1, 3 * i + 3, i + 1))
+
+
+def test_named_scene_presets(tmp_path):
+    """gpt_scene_preset: the five scenes the reference was shipped as (names only survive) + the committed default,
+    assembled from the reference's meshes, material presets and sphere table -- against the same scenes put together
+    in Python (tests/scenes.py), field for field."""
+    assert api.scene_preset_names() == ["Default", "CornellBox", "Diamond-NoDOF", "Monkey", "Speed", "Subsurface"]
+    for name in ("box", "diamond", "monkey", "coil"):
+        v, n = meshes.load_asset(name)
+        write_obj(str(tmp_path / (name + ".obj")), v, n)
+    d = str(tmp_path)
+    sph, polys, view = api.scene_preset("Default")
+    assert polys is None and np.array_equal(sph, S.default_spheres())          # (field by field: padding bytes are not data)
+    assert view == {"yaw": 0.0, "pitch": float(np.float32(0.3)), "radius": 4.0, "aperture": float(np.float32(0.04)),
+                    "fovx": 45.0, "center": (0.0, 0.0, 0.0)}
+    sph, polys, view = api.scene_preset("Speed")
+    assert polys is None and sph.size == 14 and view["aperture"] == 0.0
+    sph, polys, view = api.scene_preset("CornellBox", d)
+    bv, bn = meshes.load_asset("box")
+    assert sph.size == 14 and np.array_equal(polys, S.cornell_box(bv, bn))
+    sph, polys, view = api.scene_preset("Diamond-NoDOF", d)
+    dv, dn = meshes.load_asset("diamond")
+    want = meshes.polys_from_triangles(meshes.transform(dv, 0.8, (0.2, -2.2, 2.6)), dn, S.MATERIALS["glass"])
+    assert view["aperture"] == 0.0 and np.array_equal(polys, want)
+    sph, polys, view = api.scene_preset("Monkey", d)
+    mv, mn = meshes.load_asset("monkey")
+    want = meshes.polys_from_triangles(meshes.transform(mv, 0.5, (0.0, -0.2, 1.5)), mn, S.MATERIALS["glass"])
+    assert np.array_equal(polys, want)
+    sph, polys, view = api.scene_preset("Subsurface", d)
+    cv, cn = meshes.load_asset("coil")
+    want = np.concatenate([
+        meshes.polys_from_triangles(meshes.transform(cv, 0.25, (-1.2, -2.2, 1.2)), cn, S.MATERIALS["marble"]),
+        meshes.polys_from_triangles(meshes.transform(dv, 0.8, (0.2, -2.2, 2.6)), dn, S.MATERIALS["ketchup"])])
+    assert np.array_equal(polys, want)
+    with pytest.raises(api.GptError):
+        api.scene_preset("NoSuchScene", d)
+    with pytest.raises(api.GptError):
+        api.scene_preset("Monkey")                        # needs the mesh directory
+    with pytest.raises(api.GptError):
+        api.scene_preset("Monkey", str(tmp_path / "nowhere"))
+
+
 def test_obj_loader_errors(tmp_path):
     with pytest.raises(api.GptError) as e:
         api.obj_load(str(tmp_path / "missing.obj"))

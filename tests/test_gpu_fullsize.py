@@ -183,6 +183,28 @@ def test_headless_renderer_cli(tmp_path):
     assert raw[len(header):] == api.tonemap_8bit(img, 6).tobytes()
 
 
+def test_headless_renderer_named_scene(tmp_path):
+    """`gpt_render --scene Monkey --assets DIR`: a named scene through the CLI equals the same scene through the API."""
+    from test_cabi import write_obj
+    exe = os.path.join(ROOT, "gpupathtracer_amd", "lib", "gpt_render")
+    v, n = meshes.load_asset("monkey")
+    write_obj(str(tmp_path / "monkey.obj"), v, n)
+    ppm = str(tmp_path / "m.ppm")
+    out = subprocess.run([exe, "--width", "96", "--height", "64", "--spp", "4", "--depth", "8", "--out", ppm,
+                          "--scene", "Monkey", "--assets", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Scene Monkey: 14 spheres, 1936 triangles" in out.stdout
+    sph, polys, view = api.scene_preset("Monkey", str(tmp_path))
+    cam = api.orbit_camera(96, 64, **view)
+    with api.Scene(sph, polys, api.render_params(max_depth=8)) as sc:
+        sc.reset(96 * 64)
+        sc.render_range(cam, 0, 4)
+        img, passes = sc.accum_download()
+    raw = open(ppm, "rb").read()
+    header = b"P6\n96 64\n255\n"
+    assert raw.startswith(header) and raw[len(header):] == api.tonemap_8bit(img, 4).tobytes()
+
+
 def test_synthetic_soup_10m_4k():
     """Config: synthetic soup of 10 M triangles at 3840x2160 (the benchmark's `soup` workload)."""
     w, h, depth = 3840, 2160, 8

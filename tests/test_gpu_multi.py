@@ -65,6 +65,11 @@ def test_library_rccl_allreduce_single_scene():
         sc.render_range(cam, 0, 6)
         want, _ = sc.accum_download()
         assert passes == 6 and np.array_equal(got, want)
+        # gpt_shutdown destroys the cached communicator; the next reduce sets one up again
+        api.shutdown()
+        api.accum_allreduce([sc])
+        again, passes = sc.accum_download()
+        assert passes == 6 and np.array_equal(again, want)
         with api.Scene(sph, None, api.render_params(max_depth=2)) as other:
             other.reset(w * h)
             with pytest.raises(api.GptError):

@@ -1,7 +1,8 @@
 """Copies the judged summaries of a tools/gpu_profile.sh run into profiles/ :
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
   profiles/<tag>_pmc_summary.json   per-kernel sums of the PMC passes + derived figures
-  profiles/traffic.json             HBM-side bytes per k_intersect_kd launch (read by bench.py)
+  profiles/traffic_<workload>.json  per kernel: HBM-side bytes per launch, VALU occupancy, lane activity, L2 hit rate
+                                    and the configuration they were collected on (read by bench.py)
 Usage: collect_profiles.py gpurun_out/prof_<tag> <tag>"""
 import glob
 import json
@@ -21,7 +22,10 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
 summary = os.path.join(out, tag + "_pmc_summary.json")
 parse_prof.main(src, summary)
 d = json.load(open(summary))
-key = [k for k in d["counters"] if "k_intersect_kd<false" in k][0]
+kd_keys = [k for k in d["counters"] if "k_intersect_kd<false" in k]
+if not kd_keys:          # a scene without triangles launches no intersect kernel: the derived block describes k_shade
+    kd_keys = [k for k in d["counters"] if "k_shade" in k]
+key = kd_keys[0]
 c = d["counters"][key]
 n = c["_dispatches"]["pmc_rdreq"]
 read_bytes = 32 * c["TCC_EA0_RDREQ_32B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c["TCC_EA0_RDREQ_128B_sum"]
@@ -79,13 +83,30 @@ def per_kernel(name):
 
 d["derived_per_kernel"] = {n: per_kernel(n) for n in ("k_intersect_kd<false", "k_shade", "k_camera", "k_finish")}
 json.dump(d, open(summary, "w"), indent=1, sort_keys=True)
+# what bench.py reads: per kernel (its own names) the HBM-side bytes of one launch and the path-bounces that launch held.
+# k_intersect_kd and k_shade run once per depth on the same queues: their launches hold the same path-bounces.
+kernels = {}
+for bench_name, prof_name in (("k_intersect_kd", "k_intersect_kd<false"), ("k_shade", "k_shade")):
+    pk = d["derived_per_kernel"].get(prof_name)
+    if not pk:
+        continue
+    cc = d["counters"][pk["kernel"]]
+    n_rd, n_wr = cc["_dispatches"]["pmc_rdreq"], cc["_dispatches"]["pmc_write"]
+    kernels[bench_name] = {
+        "hbm_bytes_per_launch": pk["hbm_read_gb"] * 1e9 / n_rd + pk["hbm_write_gb"] * 1e9 / n_wr,
+        "path_bounces_per_launch": pb_per_launch, "dispatches": n_rd,
+        "valu_busy": pk["valu_busy"], "valu_lane_utilisation": pk["valu_lane_utilisation"],
+        "l2_hit_rate": pk["l2_hit_rate"], "wave_cycles_waiting": pk["wave_cycles_waiting"],
+        "hbm_tb_per_s": pk["hbm_tb_per_s"], "avg_launch_us_traced": d["kernels"][pk["kernel"]]["avg_us"],
+    }
+workload = (counter_config or {}).get("workload", "unknown")
 json.dump({
-    "k_intersect_hbm_bytes_per_launch": derived["read_bytes_per_launch"] + derived["write_bytes_per_launch"],
-    "path_bounces_per_launch": pb_per_launch,
+    "kernels": kernels,
     # bench.py reports these counters only for a run of this very configuration
     "config": counter_config,
     "how": "rocprofv3 --pmc, separate passes: sum(TCC_EA0_RDREQ_{32,64,128}B_sum x request size) + WRITE_SIZE*1024, "
-           "divided by the kernel's dispatches; bench.py --spp-per-step 1 --steps 512 --warmup 0 (8 launches of 512 passes)",
+           "divided by the kernel's dispatches; valu_busy = 4 x SQ_ACTIVE_INST_VALU / SIMD cycles, lane utilisation = "
+           "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); bench.py --spp-per-step 1 --warmup 0, one batch of passes",
     "source": tag + "_pmc_summary.json",
-}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+}, open(os.path.join(out, "traffic_%s.json" % workload), "w"), indent=1)
 print(json.dumps(derived, indent=1))
