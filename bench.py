@@ -236,7 +236,7 @@ def rank_passes(args, rank, world):
     return (base, base + Wp), (base + Wp, base + Wp + Kp)
 
 
-def dry_run(args, rank, world):
+def dry_run(args, rank, world, emit_line):
     """The launch path without a GPU: rendezvous over gloo, the ranks' pass ranges, one sum-reduce."""
     import torch
     import torch.distributed as dist
@@ -250,7 +250,7 @@ def dry_run(args, rank, world):
     else:
         gathered = [t]
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        emit_line(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": args.scaling, "passes": [int(g[0]) for g in gathered],
                           "ranges": [[int(g[1]), int(g[2])] for g in gathered],
                           # (the group the collective layer formed: gloo here, RCCL in a real run)
@@ -289,6 +289,15 @@ def main(argv=None):
     if args.gpus > 1 and not launched:
         sys.exit(spawn_ranks(args, argv))          # before anything imports torch or touches the GPU
 
+    # Only the JSON line goes to stdout: file descriptor 1 is pointed at stderr for the rest of the process (libraries
+    # such as RCCL print banners to it from C code), the line itself is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_line(text):
+        os.write(json_fd, (text + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -297,7 +306,7 @@ def main(argv=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if args.dry_run:
-        return dry_run(args, rank, world)
+        return dry_run(args, rank, world, emit_line)
 
     import torch
     import torch.distributed as dist
@@ -492,7 +501,7 @@ def main(argv=None):
             kd_fig = cpu_kd_figure(spheres, polys, cam, args.depth, scene.kd_small_threshold())
             if kd_fig is not None:
                 out["cpu_kd_traversal"] = kd_fig
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     scene.close()
     if distributed:
         dist.destroy_process_group()

@@ -1264,7 +1264,8 @@ struct LaunchCache {
     bool params_set = false;
     bool assume_static = false;
     int device = -1;
-    hipStream_t copy = nullptr;               // checksum + device-to-host copies, beside the scene's tracing stream
+    hipStream_t copy = nullptr;               // device-to-host copies (and the checksum of a first call), beside the scene's tracing stream
+    hipStream_t check = nullptr;              // the per-call checksum of a known scene: its own stream, never behind a copy
     unsigned long long* d_sum = nullptr;
     unsigned long long* h_sum = nullptr;      // pinned
     LookAhead slot[2];
@@ -1308,6 +1309,7 @@ void release_side_resources(LaunchCache& L) {
     if (L.device < 0) return;
     DeviceGuard guard(L.device);
     if (L.copy) { (void)hipStreamSynchronize(L.copy); (void)hipStreamDestroy(L.copy); L.copy = nullptr; }
+    if (L.check) { (void)hipStreamSynchronize(L.check); (void)hipStreamDestroy(L.check); L.check = nullptr; }
     if (L.d_sum) { (void)hipFree(L.d_sum); L.d_sum = nullptr; }
     if (L.h_sum) { (void)hipHostFree(L.h_sum); L.h_sum = nullptr; }
     for (LookAhead& a : L.slot) if (a.done) { (void)hipEventDestroy(a.done); a.done = nullptr; }
@@ -1351,9 +1353,15 @@ void gpt_launch_kernel_static_scene(int is_static) {
     g_launch.assume_static = is_static != 0;
 }
 
-void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, int numPixels, Color* pixels,
-                  int counter, Camera renderCamera) {
-    std::lock_guard<std::mutex> lock(g_launch.mu);
+}  // extern "C"
+
+namespace {
+// One call.  `verify_late`: the checksum of an already known scene is started at once but only waited for AFTER the
+// pass has been copied to the caller -- the answer is prepared on the assumption that the arrays are unchanged, under
+// the check's latency -- and the function returns false when the arrays turn out to have changed (the caller then
+// repeats the call with verify_late = false, which finds the change before it does anything else).
+bool launch_kernel_once(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, int numPixels, Color* pixels,
+                        int counter, const Camera& renderCamera, bool verify_late) {
     LaunchCache& L = g_launch;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { g_error = "no HIP device"; die("launchKernel:"); }
@@ -1368,6 +1376,7 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
         }
         release_side_resources(L);     // (those of the GPU the caller was on before)
         hip_or_die(hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking), "stream");
+        hip_or_die(hipStreamCreateWithFlags(&L.check, hipStreamNonBlocking), "stream");
         hip_or_die(hipMalloc((void**)&L.d_sum, 8), "hipMalloc");
         hip_or_die(hipHostMalloc((void**)&L.h_sum, 8, hipHostMallocDefault), "hipHostMalloc");
         for (LookAhead& a : L.slot) hip_or_die(hipEventCreateWithFlags(&a.done, hipEventDisableTiming), "event");
@@ -1378,17 +1387,24 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
     const bool continues = L.have_last && same_camera(L.last_cam, renderCamera) && counter == L.last_counter + 1;
     // Content checksum of the two device arrays: the scene is re-indexed only when it changes.  The reference reads
     // the arrays on every call (path_tracer_kernel.cu:805), so a caller may edit them in place between two calls: the
-    // checksum -- one pass over the arrays on the side stream (the caller's own streams are not touched) and one
+    // checksum -- one pass over the arrays on a side stream (the caller's own streams are not touched) and one
     // wait -- runs on EVERY call, unless the caller has declared the scene static.  A mismatch drops every pass traced
-    // ahead from the old contents.
+    // ahead from the old contents.  For a scene already known the wait comes last (verify_late), so that the check runs
+    // under the copy of the pass to the caller instead of in front of it.
     bool same = same_arrays;
+    bool check_pending = false;
     if (!same_arrays || !L.assume_static) {
-        hip_or_die(hipMemsetAsync(L.d_sum, 0, 8, L.copy), "hipMemset");
-        if (numPolys > 0) gptk_checksum(L.copy, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
-        if (numSpheres > 0) gptk_checksum(L.copy, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);
-        hip_or_die(hipMemcpyAsync(L.h_sum, L.d_sum, 8, hipMemcpyDeviceToHost, L.copy), "checksum readback");
-        hip_or_die(hipStreamSynchronize(L.copy), "checksum");
-        same = same_arrays && L.checksum == *L.h_sum;
+        hipStream_t cs = same_arrays ? L.check : L.copy;
+        hip_or_die(hipMemsetAsync(L.d_sum, 0, 8, cs), "hipMemset");
+        if (numPolys > 0) gptk_checksum(cs, (const uint32_t*)polys, (size_t)numPolys * sizeof(Poly) / 4, L.d_sum);
+        if (numSpheres > 0) gptk_checksum(cs, (const uint32_t*)spheres, (size_t)numSpheres * sizeof(Sphere) / 4, L.d_sum);
+        hip_or_die(hipMemcpyAsync(L.h_sum, L.d_sum, 8, hipMemcpyDeviceToHost, cs), "checksum readback");
+        if (same_arrays && verify_late) {
+            check_pending = true;          // waited for below, after the pass has been copied out
+        } else {
+            hip_or_die(hipStreamSynchronize(cs), "checksum");
+            same = same_arrays && L.checksum == *L.h_sum;
+        }
     }
     if (!same) {
         const unsigned long long sum = *L.h_sum;
@@ -1487,6 +1503,21 @@ void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, in
     L.last_counter = counter;
     L.last_cam = renderCamera;
     L.have_last = true;
+    if (check_pending) {
+        hip_or_die(hipStreamSynchronize(L.check), "checksum");
+        if (L.checksum != *L.h_sum) return false;      // the arrays were edited in place: what was handed out is stale
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+void launchKernel(int numPolys, Poly* polys, int numSpheres, Sphere* spheres, int numPixels, Color* pixels,
+                  int counter, Camera renderCamera) {
+    std::lock_guard<std::mutex> lock(g_launch.mu);
+    if (!launch_kernel_once(numPolys, polys, numSpheres, spheres, numPixels, pixels, counter, renderCamera, true))
+        launch_kernel_once(numPolys, polys, numSpheres, spheres, numPixels, pixels, counter, renderCamera, false);
 }
 
 }  // extern "C"

@@ -706,6 +706,13 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned r0u = unit * p + (unsigned)bperm(la, (int)(leafFirst - unit * excl));
                 const V3 o = v3(bperm(la, cur.o.x), bperm(la, cur.o.y), bperm(la, cur.o.z));
                 const V3 d = v3(bperm(la, cur.d.x), bperm(la, cur.d.y), bperm(la, cur.d.z));
+#ifdef ABL_BPERM_X2   // experiment: the six ray ds_bpermutes of a chunk issued a second time (what do they cost?)
+                {
+                    float x0 = bperm(la, cur.o.y), x1 = bperm(la, cur.o.z), x2 = bperm(la, cur.o.x);
+                    float x3 = bperm(la, cur.d.y), x4 = bperm(la, cur.d.z), x5 = bperm(la, cur.d.x);
+                    asm volatile("" : : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5));
+                }
+#endif
 #ifdef ABL_TRI_PAD
                 {
                     unsigned pad_ = lane;

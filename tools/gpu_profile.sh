@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --spp-per-step 1 --steps 512 --warmup 0 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --spp-per-step 1 --steps ${STEPS:-512} --warmup 0 --no-cpu-baseline $*"
 
 # ONLY="trace pmc_sq ..." restricts the run to the named passes
 run() {  # name, rocprof args...

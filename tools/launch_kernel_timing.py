@@ -29,4 +29,14 @@ for c in range(1 + n, 1 + 2 * n):
     times.append((time.perf_counter() - t1) * 1e3)
 times = np.array(times)
 print("per call: mean %.2f ms, median %.2f, 95th percentile %.2f, max %.2f" % (times.mean(), np.median(times), np.percentile(times, 95), times.max()))
+# the same with the caller's promise that the arrays do not change (no per-call checksum of the 178 MB of polys)
+api.launch_kernel_static_scene(1)
+times = []
+for c in range(1 + 2 * n, 1 + 3 * n):
+    t1 = time.perf_counter()
+    api.launch_kernel(polys.size, d_p, spheres.size, d_s, w * h, c, cam)
+    times.append((time.perf_counter() - t1) * 1e3)
+times = np.array(times)
+print("declared static: mean %.2f ms, median %.2f, 95th percentile %.2f, max %.2f" % (times.mean(), np.median(times), np.percentile(times, 95), times.max()))
+api.launch_kernel_static_scene(0)
 api.launch_kernel_params(None)
