@@ -873,7 +873,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGe
             thr = v3(th.x, th.y, th.z);
             pixel = __float_as_int(ro.w);
             medium = __float_as_int(rd.w);
-            pass = __float_as_uint(th.w);
+            // (bit 31 of the pass word: the path has added to its radiance slot before -- see the add below)
+            pass = __float_as_uint(th.w) & 0x7fffffffu;
+            bool dirty = (__float_as_uint(th.w) >> 31) != 0u;
             const float bestT = h.x;
             const int prim = __float_as_int(h.y);
 
@@ -928,13 +930,24 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGe
                 // out: it turns a -0 into the +0 the reference's accumulator would hold) instead of read-modify-write
                 st_stream(&pass_rgb[i], has_add ? make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 0.0f)
                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                dirty = has_add;
             } else if (has_add) {
+                // A slot nothing was added to since the first bounce holds +0 (stored above, by the launch that shaded
+                // the primary rays): the sum is 0 + add and needs no read -- for the usual path, whose only contribution
+                // is the sky it ends in, that halves the scattered 16-byte accesses of this kernel.
                 const size_t slot = (size_t)pixel * (size_t)numPasses + (size_t)pass;
-                float4 acc = pass_rgb[slot];
+                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (dirty) acc = pass_rgb[slot];
                 acc.x += add.x; acc.y += add.y; acc.z += add.z;
                 pass_rgb[slot] = acc;
+                dirty = true;
             }
+            pass |= dirty ? 0x80000000u : 0u;
         }
+#ifdef ABL_SHADE_SYNC   // experiment: extra block barriers per tile (what do the two of the compaction cost?)
+#pragma unroll
+        for (int q_ = 0; q_ < ABL_SHADE_SYNC; q_++) __syncthreads();
+#endif
         // ---- block compaction into the LDS staging area ----
         const unsigned long long mask = __ballot(alive);
         if (lane == 0) s_wave_cnt[wave] = (unsigned)__popcll(mask);
