@@ -178,6 +178,36 @@ def test_all_material_branches():
             assert set(np.unique(ref["events"] & 7)) >= {1, 2, 3, 4, 5} and (ref["events"] & 8).any()
 
 
+def test_paths_that_add_radiance_at_several_bounces():
+    """Glowing diffuse spheres: a path adds emitted light at every diffuse bounce and the sky when it leaves, so its
+    radiance slot is added to several times, in bounce order (accumulatedColors, path_tracer_kernel.cu:690, 712).  The
+    kernel stores the first contribution to a slot and read-modify-writes the later ones; per-sample radiance must equal
+    the oracle's in every bit, in one-pass launches and with many passes per launch."""
+    sph = S.default_spheres().copy()
+    for i in range(sph.size):
+        m = sph[i]["material"]
+        m["diffuseColor"] = (0.8, 0.7, 0.6)
+        m["emittedColor"] = (0.25 * (i % 3), 0.125, 0.0625 * (i % 5))     # some exactly zero components, some spheres dark in red
+        m["specularColor"] = (0, 0, 0)
+        m["medium"]["refractiveIndex"] = 1.0                             # no specular lobe: every hit is a diffuse bounce
+        m["hasTransmission"] = False
+    w = h = 96
+    cam = S.orbit_camera(w, h)
+    depth = 6
+    with api.Scene(sph, None, api.render_params(max_depth=depth, row_stride_is_width=0)) as sc:
+        _, ref = check_against_oracle(sc, sph, None, cam, 5, depth, 0)
+    assert ((ref["events"] & 7) == 4).sum(axis=1).max() >= 3, "the fixture needs paths with several diffuse bounces"
+    P = 8
+    with api.Scene(sph, None, api.render_params(max_depth=depth, row_stride_is_width=0, passes_in_flight=P)) as sc:
+        sc.reset(w * h)
+        sc.render_range(cam, 0, P)
+        img, passes = sc.accum_download()
+    acc = np.zeros((w * h, 3), np.float32)
+    for c in range(P):
+        acc += O.render_pass(sph, None, cam, c, O.params(max_depth=depth))["rgb"].reshape(w * h, 3)
+    assert passes == P and np.array_equal(img.view(np.int32), acc.view(np.int32))
+
+
 @pytest.mark.parametrize("use_kd", [0, 1])
 def test_mesh_scene_pass(use_kd):
     """Glass diamond + subsurface coil + spheres: brute force (the reference's loop) and kd-tree."""
