@@ -98,7 +98,7 @@ def uniform_stream(seed, n):
 def render_pass(spheres, polys, camera, counter, p, pixel_ids=None, want_hits=False, want_events=False):
     """One pass of the reference algorithm.  Returns dict(rgb, live, bounces[, hits][, events, prims]);
     events / prims: [n, max_depth], the branch code (ORC_EV_*) and primitive of every bounce."""
-    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+    spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE) if spheres is not None else np.zeros(0, SPHERE_DTYPE)
     polys = np.ascontiguousarray(polys, dtype=POLY_DTYPE) if polys is not None else np.zeros(0, POLY_DTYPE)
     cam = np.array(camera, dtype=CAMERA_DTYPE).reshape(1)
     num_pixels = int(cam["resolution"][0][0]) * int(cam["resolution"][0][1])

@@ -178,6 +178,23 @@ def test_all_material_branches():
             assert set(np.unique(ref["events"] & 7)) >= {1, 2, 3, 4, 5} and (ref["events"] & 8).any()
 
 
+@pytest.mark.parametrize("ground", [0, 1])
+def test_empty_scene(ground):
+    """No spheres and no polys (numSpheres = numPolys = 0, what the reference's loops simply skip): with the ground switched
+    off every ray ends in the sky at depth 0; with it, paths bounce between ground and sky.  Bit for bit the oracle's."""
+    w = h = 64
+    cam = S.orbit_camera(w, h)
+    depth = 5
+    with api.Scene(None, None, api.render_params(max_depth=depth, row_stride_is_width=0, ground_enabled=ground)) as sc:
+        got, ev, pr = sc.render_events(cam, 9)
+        st = sc.stats()
+    ref = O.render_pass(None, None, cam, 9, O.params(max_depth=depth, ground_enabled=ground), want_events=True)
+    parity.check_pass(got, ev, pr, ref)
+    assert st["path_bounces"] == ref["bounces"]
+    if not ground:
+        assert st["path_bounces"] == w * h and (got > 0).all()
+
+
 def test_paths_that_add_radiance_at_several_bounces():
     """Glowing diffuse spheres: a path adds emitted light at every diffuse bounce and the sky when it leaves, so its
     radiance slot is added to several times, in bounce order (accumulatedColors, path_tracer_kernel.cu:690, 712).  The
