@@ -19,7 +19,7 @@ the ranks.  A world size other than --gpus is an error.
 either way the float4 (r, g, b, passes) images are sum-reduced once with RCCL at
 the end of the timed region.
 
-Workload (BASELINE.json `metric`): the reference scene as launchKernel would
+Workload (the one the headline metric is quoted on): the reference scene as launchKernel would
 see it with its mesh path enabled on a heavy cow: the 14 default spheres,
 ground and sky (path_tracer.cpp:116-271), plus `cow_heavy` = cow.obj after 4
 rounds of 1->4 midpoint subdivision (1 485 824 triangles, all glass as
