@@ -34,8 +34,10 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
                     unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
                     unsigned leaf_min);
-void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
-                int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+int gptk_camera_masks_only(hipStream_t s, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses, unsigned* counts,
+                           uint32_t* masks);
+void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, const CamPre* cam, const uint32_t* masks,
+                int depth, uint32_t seed0, int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
                 unsigned long long* stats, unsigned char* dbg_events, int* dbg_prims, int dbg_stride);
 void gptk_finish(hipStream_t s, int grid, int numPixels, int numPasses, const float4* pass_rgb, float4* image,
@@ -281,12 +283,19 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
     if (s->profile) { gpt_status st = get_event(s, &e0); if (st) return st; HIP_TRY(hipEventRecord(s->ev_pool[e0], s->stream)); }
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(unsigned) * GPT_COUNTER_WORDS, s->stream));
-    gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, seed0,
-                s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts, s->d_sphere_mask);
-    // (the first shade launch initialises the pass radiance slots; without any bounce nobody does)
-    if (s->params.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_pass, 0, (size_t)total * sizeof(float4), s->stream));
     // every ray arrives with its closest ground / sphere hit: without triangles there is nothing to intersect
     const bool trace = s->geom.n_tris > 0 || s->kd_stats;
+    // ... and then nothing but the first shade launch would read the primary rays: it creates them itself
+    const bool fused = !trace && s->params.max_depth > 0 && total < (1ll << 32) && !getenv("GPT_NO_FUSED_CAMERA");
+    const uint32_t* fused_masks = nullptr;
+    if (fused) {
+        if (gptk_camera_masks_only(s->stream, &s->geom, &cp, N, P, counts, s->d_sphere_mask)) fused_masks = s->d_sphere_mask;
+    } else {
+        gptk_camera(s->stream, pixel_grid((int)std::min<long long>(total, 1 << 30)), &s->geom, &cp, N, P, seed0,
+                    s->d_ray_o[0], s->d_ray_d[0], s->d_thr[0], s->d_hit[0], s->d_pass, counts, s->d_sphere_mask);
+    }
+    // (the first shade launch initialises the pass radiance slots; without any bounce nobody does)
+    if (s->params.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_pass, 0, (size_t)total * sizeof(float4), s->stream));
     const int grid = (int)std::max<long long>(1, std::min<long long>(s->trace_grid, (total + kBlock - 1) / kBlock));
     for (int depth = 0; depth < s->params.max_depth; depth++) {
         const int in = depth & 1, out = in ^ 1;
@@ -301,7 +310,7 @@ gpt_status enqueue_batch(gpt_scene* s, const Camera* cam, int counter0, int P, f
             HIP_TRY(hipEventRecord(s->ev_pool[t1], s->stream));
             s->trace_pairs.push_back({t0, t1});
         }
-        gptk_shade(s->stream, grid, &s->geom, &sp, depth, seed0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
+        gptk_shade(s->stream, grid, &s->geom, &sp, (fused && depth == 0) ? &cp : nullptr, fused_masks, depth, seed0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
                    s->d_hit[in], s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_hit[out], s->d_pass, counts,
                    s->d_stats, P == 1 ? s->dbg_events : nullptr, P == 1 ? s->dbg_prims : nullptr, s->params.max_depth);
     }
@@ -815,7 +824,7 @@ gpt_status gpt_debug_dump_queue(gpt_scene* s, const Camera* cam, int counter0, i
         if (s->geom.n_tris > 0)
             gptk_intersect(s->stream, grid, &s->geom, use_kd, 0, d, s->d_ray_o[in], s->d_ray_d[in], s->d_hit[in], counts, work,
                            s->d_stats_scratch, s->d_spill, s->spill_stride, s->refill_below, s->leaf_min);
-        gptk_shade(s->stream, grid, &s->geom, &sp, d, (uint32_t)counter0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
+        gptk_shade(s->stream, grid, &s->geom, &sp, nullptr, nullptr, d, (uint32_t)counter0, P, s->d_ray_o[in], s->d_ray_d[in], s->d_thr[in],
                    s->d_hit[in], s->d_ray_o[out], s->d_ray_d[out], s->d_thr[out], s->d_hit[out], s->d_pass, counts,
                    s->d_stats_scratch, nullptr, nullptr, 0);
     }

@@ -817,8 +817,12 @@ static_assert(SHADE_FLUSH >= SHADE_BLOCK && SHADE_FLUSH % SHADE_BLOCK == 0, "SHA
 // and slot i of the still uncompacted queue belongs to pass i - pixel * numPasses.
 // DEBUG: every bounce's branch code (PT_EV_*) and primitive go to dbg_events / dbg_prims at
 // [pixel * dbg_stride + depth] (single-pass launches only; parity checks read them).
-template <bool FIRST, bool DEBUG>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, int depth, uint32_t seed0,
+// FUSED (with FIRST): a scene without triangles launches no intersect kernel, so nothing but this launch would read the
+// primary rays k_camera stores -- it creates them itself (k_camera's own functions: camera_ray, the per-pixel sphere
+// masks, the ground / sphere tests) and k_camera is not launched: 40 bytes written and 40 read per primary path less.
+template <bool FIRST, bool DEBUG, bool FUSED>
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGeometry g, ShadeParams sp, CamPre cam,
+                                                     const uint32_t* __restrict__ masks, int depth, uint32_t seed0,
                                                      int numPasses,
                                                      const float4* __restrict__ in_o,
                                                      const float4* __restrict__ in_d,
@@ -843,6 +847,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGe
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[GPT_STAT_LIVE0 + depth] += n;
     const unsigned lane = lane_id();
     const unsigned wave = threadIdx.x >> 6;
+    static_assert(!FUSED || FIRST, "only the launch of depth 0 can create the primary rays");
     // a surviving path leaves with its new ray and that ray's closest ground / sphere hit
     auto emit = [&](unsigned pos, unsigned k) {
         const float4 ro = s_o[k], rd = s_d[k];
@@ -862,12 +867,40 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_WAVES_PER_EU) void k_shade(DevGe
         V3 o = v3(0, 0, 0), d = v3(0, 0, 0), thr = v3(0, 0, 0);
         int pixel = 0, medium = -1;
         unsigned pass = 0;
+        float4 ro = make_float4(0, 0, 0, 0), rd = ro;
+        float2 h = make_float2(0, 0);
+        if (FUSED) {
+            // as k_camera does it (all lanes of the wave take part: the union of the wave's sphere masks is formed with DPP)
+            const bool in = i < n;
+            const int px = (int)((in ? i : n - 1u) / (unsigned)numPasses);
+            V3 co, cd;
+            camera_ray(cam, px, seed0 + ((in ? i : n - 1u) - (unsigned)px * (unsigned)numPasses), co, cd);
+            float bt;
+            int pr;
+            if (masks) {
+                unsigned m = in ? masks[px] : 0u;
+                GPT_DPP_STEP(dpp_or, m, 0x111, 0xf);
+                GPT_DPP_STEP(dpp_or, m, 0x112, 0xf);
+                GPT_DPP_STEP(dpp_or, m, 0x114, 0xf);
+                GPT_DPP_STEP(dpp_or, m, 0x118, 0xf);
+                GPT_DPP_STEP(dpp_or, m, 0x142, 0xa);
+                GPT_DPP_STEP(dpp_or, m, 0x143, 0xc);
+                analytic_hits_masked(g, co, cd, (uint32_t)__builtin_amdgcn_readlane((int)m, 63), bt, pr);
+            } else {
+                analytic_hits(g, co, cd, bt, pr);
+            }
+            ro = make_float4(co.x, co.y, co.z, __int_as_float(px));
+            rd = make_float4(cd.x, cd.y, cd.z, __int_as_float(-1));
+            h = make_float2(bt, __int_as_float(pr));
+        }
         if (i < n) {
-            const float4 ro = ld_stream(&in_o[i]);
-            const float4 rd = ld_stream(&in_d[i]);
+            if (!FUSED) {
+                ro = ld_stream(&in_o[i]);
+                rd = ld_stream(&in_d[i]);
+                h = ld_stream(&hit[i]);
+            }
             const float4 th = FIRST ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(i - (unsigned)__float_as_int(ro.w) * (unsigned)numPasses))
                                     : ld_stream(&in_thr[i]);
-            const float2 h = ld_stream(&hit[i]);
             o = v3(ro.x, ro.y, ro.z);
             d = v3(rd.x, rd.y, rd.z);
             thr = v3(th.x, th.y, th.z);
@@ -1156,6 +1189,19 @@ void gptk_camera(hipStream_t s, int grid, const DevGeometry* g, const CamPre* ca
                        thr, hit, pass_rgb, counts, masks);
 }
 
+// What is left of gptk_camera when the first shade launch creates the primary rays: the per-pixel sphere masks (if the
+// scene's spheres allow them: returns whether it wrote them) and the length of the primary queue.
+__global__ void k_set_count(unsigned* counts, unsigned total) { counts[0] = total; }
+int gptk_camera_masks_only(hipStream_t s, const DevGeometry* g, const CamPre* cam, int numPixels, int numPasses, unsigned* counts,
+                           uint32_t* masks) {
+    if (masks && (g->n_spheres < 1 || g->n_spheres > 32)) masks = nullptr;
+    if (masks)
+        hipLaunchKernelGGL(k_camera_masks, dim3((numPixels + GPT_BLOCK - 1) / GPT_BLOCK), dim3(GPT_BLOCK), 0, s, *g, *cam,
+                           numPixels, masks);
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, counts, (unsigned)numPixels * (unsigned)numPasses);
+    return masks != nullptr;
+}
+
 void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, int stats_on, int depth,
                     const float4* ray_o, const float4* ray_d, float2* hit, unsigned* counts, unsigned* work,
                     unsigned long long* stats, uint32_t* spill, size_t spill_stride, unsigned refill_below,
@@ -1185,17 +1231,23 @@ void gptk_intersect(hipStream_t s, int grid, const DevGeometry* g, int use_kd, i
     }
 }
 
-void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, int depth, uint32_t seed0,
-                int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
+// cam (with depth == 0): the launch creates the primary rays itself (k_camera was not launched; counts[0] holds their number),
+// with the per-pixel sphere masks `masks` or, without them, testing every sphere
+void gptk_shade(hipStream_t s, int grid, const DevGeometry* g, const ShadeParams* sp, const CamPre* cam, const uint32_t* masks,
+                int depth, uint32_t seed0, int numPasses, const float4* in_o, const float4* in_d, const float4* in_thr, const float2* hit, float4* out_o,
                 float4* out_d, float4* out_thr, float2* out_hit, float4* pass_rgb, unsigned* counts,
                 unsigned long long* stats, unsigned char* dbg_events, int* dbg_prims, int dbg_stride) {
-#define GPT_LAUNCH_SHADE(FIRST, DEBUG)                                                                                       \
-    hipLaunchKernelGGL((k_shade<FIRST, DEBUG>), dim3(blocks), dim3(SHADE_BLOCK), 0, s, *g, *sp, depth, seed0, numPasses, in_o, in_d, \
+#define GPT_LAUNCH_SHADE(FIRST, DEBUG, FUSED)                                                                                \
+    hipLaunchKernelGGL((k_shade<FIRST, DEBUG, FUSED>), dim3(blocks), dim3(SHADE_BLOCK), 0, s, *g, *sp, camv, masks, depth, seed0, numPasses, in_o, in_d, \
                        in_thr, hit, out_o, out_d, out_thr, out_hit, pass_rgb, counts, stats, dbg_events, dbg_prims, dbg_stride)
     const bool debug = dbg_events != nullptr && dbg_prims != nullptr;
+    CamPre camv = {};
+    if (cam) camv = *cam;
+    if (masks && (g->n_spheres < 1 || g->n_spheres > 32)) masks = nullptr;
     const int blocks = grid * GPT_BLOCK / SHADE_BLOCK > 0 ? grid * GPT_BLOCK / SHADE_BLOCK : 1;   // `grid` counts 256-thread blocks
-    if (depth == 0) { if (debug) GPT_LAUNCH_SHADE(true, true); else GPT_LAUNCH_SHADE(true, false); }
-    else { if (debug) GPT_LAUNCH_SHADE(false, true); else GPT_LAUNCH_SHADE(false, false); }
+    if (depth == 0 && cam) { if (debug) GPT_LAUNCH_SHADE(true, true, true); else GPT_LAUNCH_SHADE(true, false, true); }
+    else if (depth == 0) { if (debug) GPT_LAUNCH_SHADE(true, true, false); else GPT_LAUNCH_SHADE(true, false, false); }
+    else { if (debug) GPT_LAUNCH_SHADE(false, true, false); else GPT_LAUNCH_SHADE(false, false, false); }
 #undef GPT_LAUNCH_SHADE
 }
 
