@@ -287,6 +287,11 @@ __global__ __launch_bounds__(GPT_BLOCK) void k_camera(DevGeometry g, CamPre cam,
 #define KD_WAVES_PER_EU 7
 #endif
 
+// v_min / v_max as they are: the other operand for a NaN one, and none of the canonicalising extra instructions the
+// compiler wraps around fminf / fmaxf.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 struct DevStack {
     // An entry is two words.  Word 1 is tmin with its low 11 bits cleared (rounded DOWN by at most 2.4e-4 of
     // itself: the stored interval starts a little early); the interval's LENGTH tmax - tmin, rounded UP to its upper 16
@@ -295,10 +300,18 @@ struct DevStack {
     // < 1 % of itself costs next to nothing -- rounding tmax itself would misplace the end by 1 % of the DISTANCE,
     // many leaves' worth far from the origin.  Two words instead of three mean one LDS instruction per push or pop
     // (an LDS write costs a SIMD 18 - 27 cycles: tools/microbench/valu_issue.hip) and room for one more wave per SIMD.
+    //
+    // The stored tmin never increases towards the top of the stack: a new entry's tmin is lowered to the tmin of the
+    // entry it is pushed onto if it lies above it (front-to-back traversal pushes in that order anyway; the thickened
+    // planes break it by a slack now and then, and starting an interval early is always allowed).  So when the closest
+    // hit lies in front of the TOP entry it lies in front of every entry, and a traversal ends with one look at the
+    // stack instead of one pop per entry left -- that loop was 128 M wave iterations per 64 passes of the benchmark
+    // frame, next to 224 M walk iterations.  `top` is the top entry's stored tmin (+infinity: stack empty).
     uint32_t* lds;          // this thread's column of words: lds[(2*e + c) * GPT_BLOCK]
     uint32_t* spill;        // this thread's column: spill[(2*e + c) * spill_stride]
     unsigned spill_stride;  // (2 * depth * stride fits 32 bits: checked by the host)
     int sp, lo;             // entries [lo, sp) are in LDS, [0, lo) in the spill buffer
+    float top;
 
     static __device__ __forceinline__ void pack(uint32_t node, float tmin, float tmax, uint32_t& w0, uint32_t& w1) {
         const uint32_t t0 = __float_as_uint(tmin) & ~0x7ffu;
@@ -317,7 +330,7 @@ struct DevStack {
     // The spill path uses non-temporal accesses: written once, read once -- and a different
     // kind of access than the LDS path's, so the compiler cannot merge the two into generic
     // flat accesses.
-    __device__ __forceinline__ void reset() { sp = 0; lo = 0; }
+    __device__ __forceinline__ void reset() { sp = 0; lo = 0; top = __uint_as_float(0x7f800000u); }
     __device__ __forceinline__ void push(uint32_t node, float tmin, float tmax) {
         const int slot = (int)((unsigned)sp % KD_LDS_N);
         // (asked of the whole wave first: a spill is rare, and a uniform branch around it costs one scalar instruction
@@ -331,9 +344,10 @@ struct DevStack {
             }
         }
         uint32_t w0, w1;
-        pack(node, tmin, tmax, w0, w1);
+        pack(node, vmin(tmin, top), tmax, w0, w1);
         lds[(2 * slot + 0) * GPT_BLOCK] = w0;
         lds[(2 * slot + 1) * GPT_BLOCK] = w1;
+        top = __uint_as_float(w1 & ~0x7ffu);
         sp++;
     }
     // pop() for the lanes in `take` (each of which has an entry), executed by the whole wave: the other lanes read
@@ -345,18 +359,26 @@ struct DevStack {
         // generic flat loads
         const int slot = (int)((unsigned)sp % KD_LDS_N);
         uint32_t w0 = lds[(2 * slot + 0) * GPT_BLOCK], w1 = lds[(2 * slot + 1) * GPT_BLOCK];
-        asm volatile("" : "+v"(w0), "+v"(w1));   // the values, not the addresses, meet below
-        const KdPred spilled = take & KdPred::of(sp < lo);
+        // ... and the tmin word of the entry below, the new top
+        const int below = (int)((unsigned)(sp - 1) % KD_LDS_N);
+        uint32_t wb = lds[(2 * below + 1) * GPT_BLOCK];
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(wb));   // the values, not the addresses, meet below
+        const KdPred spilled = take & KdPred::of(sp - 1 < lo);   // the popped entry or the one below it lives in the spill buffer
         if (spilled.bits() != 0ull) {
             asm volatile("");
             if (spilled.on()) {
-                w0 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 0) * spill_stride);
-                w1 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 1) * spill_stride);
-                asm volatile("" : "+v"(w0), "+v"(w1));   // wait here, in the rare branch, not at a later join
-                lo = sp;
+                if (sp < lo) {
+                    w0 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 0) * spill_stride);
+                    w1 = __builtin_nontemporal_load(spill + (unsigned)(2 * sp + 1) * spill_stride);
+                    lo = sp;
+                }
+                if (sp > 0) wb = __builtin_nontemporal_load(spill + (unsigned)(2 * (sp - 1) + 1) * spill_stride);
+                asm volatile("" : "+v"(w0), "+v"(w1), "+v"(wb));   // wait here, in the rare branch, not at a later join
             }
         }
         unpack(w0, w1, node, tmin, tmax);
+        const float below_tmin = sp > 0 ? __uint_as_float(wb & ~0x7ffu) : __uint_as_float(0x7f800000u);
+        top = take.on() ? below_tmin : top;
     }
 };
 
@@ -460,10 +482,6 @@ __device__ __forceinline__ float bperm(unsigned byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_addr, __float_as_int(v)));
 }
 
-// v_min / v_max as they are: the other operand for a NaN one, and none of the canonicalising extra instructions the
-// compiler wraps around fminf / fmaxf.
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // kd_root_interval without a branch (the per-axis special case of a zero direction component costs the wave three
 // divergent regions there).  The reciprocals are clamped to +-1e30 -- as good as infinite for any scene -- so that
@@ -753,25 +771,22 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
             __builtin_amdgcn_wave_barrier();
         }
         // ---- next interval ----
-        // The lanes that waited at a leaf take the next deferred interval that can still hold a closer (or equal) hit;
-        // a lane that has none left is done.  One stack entry per iteration for all lanes that still look, the loop
-        // itself on a wave-uniform condition.
+        // The lanes that waited at a leaf take their next deferred interval if it can still hold a closer (or equal) hit;
+        // a lane that has none left, or whose next one starts behind its closest hit, is done.
         {
             const unsigned long long key = __atomic_load_n(&s_best[threadIdx.x], __ATOMIC_RELAXED);
             const float bestT = __uint_as_float((unsigned)(key >> 32));
-            KdPred needM = parkedM, doneM = KdPred::none();
-            while (needM.bits() != 0ull) {
-                const KdPred takeM = needM & KdPred::of(cur.st.sp != 0);
-                doneM = doneM | (needM & ~takeM);
-                uint32_t node_;
-                float tmin_, tmax_;
-                cur.st.pop_if(takeM, node_, tmin_, tmax_);
-                const KdPred acceptM = takeM & ~KdPred::of(bestT < tmin_);
-                cur.node = acceptM.on() ? node_ : cur.node;
-                cur.tmin = acceptM.on() ? tmin_ : cur.tmin;
-                cur.tmax = acceptM.on() ? vmin(tmax_, bestT) : cur.tmax;
-                needM = takeM & ~acceptM;
-            }
+            // (the stack's tmin values do not increase towards the top -- DevStack --, so a top entry that starts behind
+            // the closest hit ends the traversal: every other entry starts behind it, too)
+            const KdPred takeM = parkedM & KdPred::of(cur.st.sp != 0);
+            uint32_t node_;
+            float tmin_, tmax_;
+            cur.st.pop_if(takeM, node_, tmin_, tmax_);
+            const KdPred acceptM = takeM & ~KdPred::of(bestT < tmin_);
+            cur.node = acceptM.on() ? node_ : cur.node;
+            cur.tmin = acceptM.on() ? tmin_ : cur.tmin;
+            cur.tmax = acceptM.on() ? vmin(tmax_, bestT) : cur.tmax;
+            const KdPred doneM = parkedM & ~acceptM;
             // The traversal of these lanes is over: a triangle that beat the ground / sphere hit replaces it in the ray's hit slot.
             const unsigned tri1 = (unsigned)key;     // triangle index + 1, or 0
             if (doneM.on() && tri1 != 0u) hit[slot] = make_float2(bestT, __int_as_float((int)(tri1 - 1u)));
