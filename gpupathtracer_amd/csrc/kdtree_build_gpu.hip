@@ -15,6 +15,7 @@
 // equal values, which decides the sign of a zero) are reproduced with 64-bit atomic keys
 // (value, item position).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
@@ -608,6 +609,15 @@ inline int blocks(size_t n) { return (int)((n + kB - 1) / kB); }
 // in *err); the caller may fall back to build().
 bool build_gpu(const float* verts, int n_tris, const BuildParams& bp, Tree& out, std::string* err) {
     if (n_tris <= 0) { build(verts, n_tris, bp, out); return true; }
+    // Fault injection for the tests of the callers' fallback to the host builder: GPT_TEST_FAIL_GPU_BUILD=k makes the
+    // k-th call of this function in the process fail the way an exhausted device would.
+    if (const char* e = getenv("GPT_TEST_FAIL_GPU_BUILD")) {
+        static std::atomic<int> calls{0};
+        if (++calls == atoi(e)) {
+            if (err) *err = "kd-tree build on the GPU failed (injected by GPT_TEST_FAIL_GPU_BUILD)";
+            return false;
+        }
+    }
     DevPool pool;
     float* d_verts = pool.get<float>((size_t)n_tris * 9);
     unsigned long long* d_root_keys = pool.get<unsigned long long>(6);

@@ -60,3 +60,29 @@ def test_sah_stage_threshold_is_chosen_per_scene():
                 sizes[small] = (info["kd_nodes"], info["kd_refs"], info["kd_depth"])
         assert sizes[12] != sizes[96]
         assert sizes[0] == sizes[want], (sizes, want)
+
+
+def test_scene_create_falls_back_to_the_host_builder(monkeypatch, capfd):
+    """gpt_scene_create indexes a mesh of this size on the GPU, twice (the per-scene choice of the SAH stage threshold builds
+    two trees).  When the second of those builds fails, the host builder -- which builds the same tree word for word --
+    takes over for it: same tree statistics, same choice, same hits as a scene created without the failure."""
+    v, n = meshes.load_asset("cow")
+    v, n = meshes.subdivide(v, n, 3)                                   # 371 456 triangles: above the GPU builder's threshold
+    polys = meshes.polys_from_triangles(v, n, api.material_preset("glass"))
+    rng = np.random.default_rng(3)
+    lo, hi = v.reshape(-1, 3).min(axis=0), v.reshape(-1, 3).max(axis=0)
+    o = (rng.random((20000, 3), dtype=np.float32) * 3 - 1) * (hi - lo) + lo
+    d = (rng.random((20000, 3), dtype=np.float32) - 0.5)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    with api.Scene(None, polys, api.render_params(max_depth=1)) as sc:
+        info0, small0 = sc.info(), sc.kd_small_threshold()
+        tri0, t0 = sc.intersect(rays, use_kdtree=True)
+    monkeypatch.setenv("GPT_TEST_FAIL_GPU_BUILD", "2")    # (counts the GPU builds made while the variable is set)
+    with api.Scene(None, polys, api.render_params(max_depth=1)) as sc:
+        info1, small1 = sc.info(), sc.kd_small_threshold()
+        tri1, t1 = sc.intersect(rays, use_kdtree=True)
+    err = capfd.readouterr().err
+    assert "building the kd-tree on the host instead" in err
+    assert info0 == info1 and small0 == small1
+    assert np.array_equal(tri0, tri1) and np.array_equal(t0.view(np.int32), t1.view(np.int32))
