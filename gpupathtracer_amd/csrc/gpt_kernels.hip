@@ -363,7 +363,9 @@ struct DevStack {
         const int below = (int)((unsigned)(sp - 1) % KD_LDS_N);
         uint32_t wb = lds[(2 * below + 1) * GPT_BLOCK];
         asm volatile("" : "+v"(w0), "+v"(w1), "+v"(wb));   // the values, not the addresses, meet below
-        const KdPred spilled = take & KdPred::of(sp - 1 < lo);   // the popped entry or the one below it lives in the spill buffer
+        // the popped entry or the one below it lives in the spill buffer (lo > 0: only after a spill; a stack that merely
+        // runs empty does not come here)
+        const KdPred spilled = take & KdPred::of(sp <= lo && lo > 0);
         if (spilled.bits() != 0ull) {
             asm volatile("");
             if (spilled.on()) {
