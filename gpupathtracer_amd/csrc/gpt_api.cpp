@@ -174,8 +174,8 @@ struct gpt_scene {
     int numPixels = 0;
     int batch = 1;                           // passes traced together per launch
     int trace_grid = kTraceGrid;             // workgroups of the intersect / shade launches of a batch (launchKernel leaves room for its checksum)
-    unsigned refill_below = 40;              // k_intersect_kd: refill a wave when fewer lanes are busy
-    unsigned leaf_min = 24;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
+    unsigned refill_below = 28;              // k_intersect_kd: refill a wave when fewer lanes are busy
+    unsigned leaf_min = 20;                  // k_intersect_kd: test triangles once this many lanes wait at a leaf
     float4* d_ray_o[2] = {nullptr, nullptr};
     float4* d_ray_d[2] = {nullptr, nullptr};
     float4* d_thr[2] = {nullptr, nullptr};
@@ -1446,8 +1446,9 @@ bool launch_kernel_once(int numPolys, Poly* polys, int numSpheres, Sphere* spher
     gpt_scene* s = L.scene;
     // The batches traced ahead fill the GPU with workgroups that stay until their launch is done (eight per CU take
     // every wave slot), and the per-call checksum, a kernel on another stream, would now and then wait for a whole
-    // launch to end -- with the caller waiting behind it (every 20th call took 2.4 ms instead of 0.9).  Six workgroups
-    // per CU trace 3 % slower and leave the checksum its slots; a scene declared static needs none.
+    // launch to end -- with the caller waiting behind it (every 20th call took 2.3 ms instead of 0.9).  Six workgroups
+    // per CU trace 9 % slower and leave the checksum its slots (mean per call 1.03 ms instead of 1.19); a scene declared
+    // static needs none.
     s->trace_grid = L.assume_static ? kTraceGrid : kTraceGrid / 8 * 6;
     if (const char* e = getenv("GPT_LAUNCH_GRID")) s->trace_grid = std::max(1, std::min(kTraceGrid, atoi(e)));
     DeviceGuard device_guard_(s->device);

@@ -17,7 +17,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+for f in parse_prof.newest(os.path.join(src, "trace", "**", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(out, tag + "_kernel_stats.csv"))
 summary = os.path.join(out, tag + "_pmc_summary.json")
 parse_prof.main(src, summary)

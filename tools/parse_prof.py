@@ -17,9 +17,16 @@ def short(name):
     return name.split("(")[0][:60]
 
 
+def newest(pattern):
+    """The most recent file matching `pattern` (results of repeated runs merged into one directory keep the older
+    runs' files, named by process id, beside the new ones)."""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def main(d, out):
     res = {"kernels": {}, "counters": {}}
-    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(d, "trace", "**", "*kernel_trace.csv")):
         agg = defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -30,7 +37,7 @@ def main(d, out):
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         if not os.path.isdir(sub):
             continue
-        for f in glob.glob(os.path.join(sub, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(os.path.join(sub, "**", "*counter_collection.csv")):
             agg = defaultdict(lambda: defaultdict(float))
             calls = defaultdict(set)
             for r in csv.DictReader(open(f)):
