@@ -571,6 +571,15 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
     // parts when its own is exhausted.
     unsigned part = blockIdx.x & (GPT_WORK_PARTS - 1u), parts_done = 0;
     unsigned local_next = 0, local_end = 0;
+    // A short queue (one pass per launch, a caller's ray set) in chunks of KD_FETCH_CHUNK would occupy a fraction of the
+    // grid's waves, each working through its 512 rays 30 at a time: the chunk shrinks until every wave gets two.
+    unsigned chunk = KD_FETCH_CHUNK;
+#ifndef KD_FIXED_CHUNK
+    {
+        const unsigned per_wave = n / (gridDim.x * (GPT_BLOCK / 64u) * 2u);
+        if (per_wave < KD_FETCH_CHUNK) chunk = per_wave < 64u ? 64u : (per_wave & ~63u);
+    }
+#endif
     for (;;) {
         // ---- refill ----
         while (!drained) {
@@ -582,14 +591,14 @@ __global__ __launch_bounds__(GPT_BLOCK, KD_WAVES_PER_EU) void k_intersect_kd(Dev
                 const unsigned part_lo = (unsigned)((unsigned long long)n * part / GPT_WORK_PARTS);
                 const unsigned part_hi = (unsigned)((unsigned long long)n * (part + 1u) / GPT_WORK_PARTS);
                 const unsigned base = part_lo + wave_fetch(&work[(depth * GPT_WORK_PARTS + part) * GPT_WORK_STRIDE],
-                                                           KD_FETCH_CHUNK);
+                                                           chunk);
                 if (base >= part_hi) {
                     part = (part + 1u) & (GPT_WORK_PARTS - 1u);
                     if (++parts_done == GPT_WORK_PARTS) drained = true;
                     continue;
                 }
                 local_next = base;
-                local_end = (base + KD_FETCH_CHUNK < part_hi) ? base + KD_FETCH_CHUNK : part_hi;
+                local_end = (base + chunk < part_hi) ? base + chunk : part_hi;
             }
             const unsigned avail = local_end - local_next;
             const unsigned take = cnt < avail ? cnt : avail;
